@@ -1,0 +1,320 @@
+"""OCP description of the path-parametric bicycle NMPC (host side, NumPy only).
+
+Mirrors the reference's solver factory module ``python/mpc.py`` (``ModelBounds`` :18-26,
+``get_acados_ocp`` :29-101, ``get_acados_solver`` :104-113) and the model wrappers of
+``python/models.py:809-843``.  The reference fills an ``acados_template.AcadosOcp``; here the same
+attribute tree (``ocp.dims``, ``ocp.cost``, ``ocp.constraints``, ``ocp.solver_options``) is a set of
+plain dataclasses, and :meth:`AcadosOcp.flatten` turns it into the dense arrays the C-ABI
+(``include/ihm2mpc.h``) takes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .constants import NG, NU, NX, NY, t_delta, t_T
+
+INF = float("inf")
+
+MODEL_FKIN6 = 0
+MODEL_FDYN6 = 1
+_MODEL_IDS = {"fkin6": MODEL_FKIN6, "fdyn6": MODEL_FDYN6}
+INTEG_RK4 = 0
+
+
+@dataclass
+class ModelBounds:
+    """``python/mpc.py:18-26`` (a pydantic model there)."""
+
+    n_max: float = 2.0
+    v_x_min: float = 0.0
+    v_x_max: float = 31.0
+    T_max: float = 500.0
+    delta_max: float = 0.5
+    T_dot_max: float = 1e6
+    delta_dot_max: float = 1.0
+    a_lat_max: float = 5.0
+
+
+# ---- model wrappers (python/models.py:232-307, 455-606, 809-843) -------------------------------
+def fkin6_model(x=None, u=None, p=None):
+    """Frenet kinematic 6-DOF bicycle model; the arithmetic lives in the HIP kernels
+    (``csrc/ihm2mpc_kernels.hip``).  Kept as a callable token so call sites read like the reference."""
+    return "fkin6"
+
+
+def fdyn6_model(xdot=None, x=None, u=None, p=None):
+    """Frenet dynamic 4-wheel Pacejka model (implicit in the reference; solved for xdot on device)."""
+    return "fdyn6"
+
+
+@dataclass
+class AcadosModel:
+    name: str = "ihm2_fkin6"
+    kind: str = "fkin6"
+    nx: int = NX
+    nu: int = NU
+    np_: int = 3000
+
+    @property
+    def model_id(self) -> int:
+        return _MODEL_IDS[self.kind]
+
+
+def _dim(v, default):
+    if v is None:
+        return default
+    if isinstance(v, int):
+        return v
+    return int(np.asarray(v).shape[0])
+
+
+def get_acados_model_from_explicit_dynamics(name, continuous_model_fn, x=None, u=None, p=None) -> AcadosModel:
+    """``python/models.py:809-825``.  ``x``, ``u``, ``p`` may be ints or arrays (only sizes matter)."""
+    kind = continuous_model_fn() if callable(continuous_model_fn) else str(continuous_model_fn)
+    if kind not in _MODEL_IDS:
+        raise ValueError(f"unknown model {kind!r}")
+    return AcadosModel(name=name, kind=kind, nx=_dim(x, NX), nu=_dim(u, NU), np_=_dim(p, 3000))
+
+
+def get_acados_model_from_implicit_dynamics(name, continuous_model_fn, x=None, u=None, p=None) -> AcadosModel:
+    """``python/models.py:828-843``."""
+    return get_acados_model_from_explicit_dynamics(name, continuous_model_fn, x, u, p)
+
+
+# ---- AcadosOcp-shaped containers -----------------------------------------------------------------
+@dataclass
+class AcadosOcpDims:
+    N: int = 40
+    nx: int = NX
+    nu: int = NU
+    np: int = 3000
+    ny: int = NY
+    ny_e: int = NX
+
+
+@dataclass
+class AcadosOcpCost:
+    cost_type: str = "LINEAR_LS"
+    cost_type_e: str = "LINEAR_LS"
+    W: np.ndarray = field(default_factory=lambda: np.eye(NY))
+    Vx: np.ndarray = field(default_factory=lambda: np.zeros((NY, NX)))
+    Vu: np.ndarray = field(default_factory=lambda: np.zeros((NY, NU)))
+    W_e: np.ndarray = field(default_factory=lambda: np.eye(NX))
+    Vx_e: np.ndarray = field(default_factory=lambda: np.eye(NX))
+    yref: np.ndarray = field(default_factory=lambda: np.ones(NY))
+    yref_e: np.ndarray = field(default_factory=lambda: np.ones(NX))
+
+
+@dataclass
+class AcadosOcpConstraints:
+    x0: np.ndarray = field(default_factory=lambda: np.ones(NX))
+    idxbx: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    lbx: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    ubx: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    idxbx_e: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    lbx_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    ubx_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    idxbu: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    lbu: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    ubu: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    C: np.ndarray = field(default_factory=lambda: np.zeros((NG, NX)))
+    D: np.ndarray = field(default_factory=lambda: np.zeros((NG, NU)))
+    lg: np.ndarray = field(default_factory=lambda: np.full(NG, -INF))
+    ug: np.ndarray = field(default_factory=lambda: np.full(NG, INF))
+
+
+@dataclass
+class AcadosOcpOptions:
+    """Subset of ``acados_template.AcadosOcpOptions`` the reference sets (``python/main.py:227-238``,
+    ``old/generate.py:18-26``) plus the knobs of this implementation."""
+
+    tf: float = 2.0
+    qp_solver: str = "PARTIAL_CONDENSING_HPIPM"   # accepted for drop-in; the QP is solved full-space (Riccati IPM)
+    nlp_solver_type: str = "SQP_RTI"              # "SQP_RTI" (old/generate.py:21) or "SQP" (python/main.py:230)
+    nlp_solver_max_iter: int = 1
+    hessian_approx: str = "GAUSS_NEWTON"
+    hpipm_mode: str = "SPEED_ABS"
+    integrator_type: str = "ERK"                  # RK4 x sim_method_num_steps (old/generate.py:23-25)
+    sim_method_num_stages: int = 4
+    sim_method_num_steps: int = 25                # M; 1 is unstable on this model
+    globalization: str = "FIXED_STEP"
+    print_level: int = 0
+    # implementation knobs
+    qp_solver_iter_max: int = 30
+    qp_tol: float = 1e-6                          # relative (see csrc: scaled by |g|_inf and |b|_inf); ~sqrt(eps) is the fp64 limit
+    qp_mu0: float = 0.03               # initial barrier parameter = qp_mu0 * max(1, |g|_inf)
+    qp_tau0: float = 0.1
+    cost_scale_stage: float | None = None         # None -> time step (acados scales stage cost by dt)
+    nlp_tol: float = 1e-6                         # SQP mode: stop when all four KKT residuals <= tol
+
+
+@dataclass
+class AcadosOcp:
+    model: AcadosModel = field(default_factory=AcadosModel)
+    dims: AcadosOcpDims = field(default_factory=AcadosOcpDims)
+    cost: AcadosOcpCost = field(default_factory=AcadosOcpCost)
+    constraints: AcadosOcpConstraints = field(default_factory=AcadosOcpConstraints)
+    solver_options: AcadosOcpOptions = field(default_factory=AcadosOcpOptions)
+    parameter_values: np.ndarray | None = None
+    code_export_directory: str = ""
+
+    def flatten(self) -> "OcpData":
+        return OcpData.from_ocp(self)
+
+
+def get_acados_ocp(
+    model: AcadosModel,
+    Nf: int,
+    n_max: float,
+    v_x_max: float,
+    T_max: float,
+    delta_max: float,
+    T_dot_max: float,
+    delta_dot_max: float,
+) -> AcadosOcp:
+    """Same signature and content as ``python/mpc.py:29-101``."""
+    ocp = AcadosOcp()
+    ocp.model = model
+    ocp.dims.N = Nf
+    ocp.dims.nx = nx = model.nx
+    ocp.dims.nu = nu = model.nu
+    ocp.dims.np = model.np_
+    # stage cost y = Vx x + Vu u = [x; u; x[-nu:] - u]  (mpc.py:49-58)
+    ocp.dims.ny = ny = nx + nu + nu
+    ocp.cost.W = np.eye(ny)
+    Vx = np.zeros((ny, nx))
+    Vx[:nx] = np.eye(nx)
+    Vx[-nu:, -nu:] = np.eye(nu)
+    Vu = np.zeros((ny, nu))
+    Vu[-2 * nu:-nu] = np.eye(nu)
+    Vu[-nu:] = -np.eye(nu)
+    ocp.cost.Vx, ocp.cost.Vu = Vx, Vu
+    ocp.dims.ny_e = nx
+    ocp.cost.W_e = np.eye(nx)
+    ocp.cost.Vx_e = np.eye(nx)
+    ocp.cost.yref = np.ones(ny)
+    ocp.cost.yref_e = np.ones(nx)
+    ocp.constraints.x0 = np.ones(nx)
+    ocp.parameter_values = np.ones(model.np_)
+    # state boxes (mpc.py:79-84); the terminal index set [1,3,4,5] is reproduced as written (quirk Q1)
+    c = ocp.constraints
+    c.idxbx = np.array([1, 3, 6, 7])
+    c.lbx = np.array([-n_max, 0.0, -T_max, -delta_max])
+    c.ubx = np.array([n_max, v_x_max, T_max, delta_max])
+    c.idxbx_e = np.array([1, 3, 4, 5])
+    c.lbx_e = np.array([-n_max, -v_x_max, -T_max, -delta_max])
+    c.ubx_e = np.array([n_max, v_x_max, T_max, delta_max])
+    # control boxes (mpc.py:87-89)
+    c.idxbu = np.array([0, 1])
+    c.lbu = np.array([-T_max, -delta_max])
+    c.ubu = np.array([T_max, delta_max])
+    # rate rows g = C x + D u = u - x[6:8]  (mpc.py:92-99)
+    c.C = np.zeros((2, nx))
+    c.C[0, -2] = -1.0
+    c.C[1, -1] = -1.0
+    c.D = np.zeros((2, nu))
+    c.D[0, 0] = 1.0
+    c.D[1, 1] = 1.0
+    c.lg = np.array([t_T * -T_dot_max, t_delta * -delta_dot_max])
+    c.ug = np.array([t_T * T_dot_max, t_delta * delta_dot_max])
+    return ocp
+
+
+# ---- dense, per-stage arrays handed to the C-ABI ---------------------------------------------------
+@dataclass
+class OcpData:
+    N: int
+    M: int
+    dt: float
+    model: int
+    integrator: int
+    cost_scale_stage: float
+    W: np.ndarray      # (N,12,12)
+    W_e: np.ndarray    # (8,8)
+    lbx: np.ndarray    # (N+1,8), +-inf = absent, row 0 unused
+    ubx: np.ndarray
+    lbu: np.ndarray    # (N,2)
+    ubu: np.ndarray
+    C: np.ndarray      # (N,2,8)
+    D: np.ndarray      # (N,2,2)
+    lg: np.ndarray     # (N,2)
+    ug: np.ndarray
+    ipm_iter_max: int
+    ipm_tol: float
+    ipm_mu0: float
+    ipm_tau0: float
+    nlp_solver_type: str = "SQP_RTI"
+    nlp_solver_max_iter: int = 1
+    nlp_tol: float = 1e-6
+
+    @staticmethod
+    def from_ocp(ocp: AcadosOcp) -> "OcpData":
+        o, d, c = ocp.solver_options, ocp.dims, ocp.constraints
+        N = d.N
+        if (d.nx, d.nu, d.ny, d.ny_e) != (NX, NU, NY, NX):
+            raise ValueError("this implementation is specialised to nx=8, nu=2, ny=12, ny_e=8")
+        if ocp.cost.cost_type != "LINEAR_LS" or ocp.cost.cost_type_e != "LINEAR_LS":
+            raise ValueError("only LINEAR_LS costs (python/mpc.py:49,62)")
+        ref = get_acados_ocp(ocp.model, N, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0)
+        if not (np.array_equal(ocp.cost.Vx, ref.cost.Vx) and np.array_equal(ocp.cost.Vu, ref.cost.Vu)
+                and np.array_equal(ocp.cost.Vx_e, np.eye(NX))):
+            raise ValueError("output selectors Vx, Vu, Vx_e are fixed to those of python/mpc.py:51-64")
+        if o.integrator_type != "ERK":
+            raise ValueError("integrator_type must be 'ERK' (RK4 x sim_method_num_steps); IRK is not implemented")
+        if o.sim_method_num_stages != 4:
+            raise ValueError("ERK is the classical 4-stage RK4")
+        if o.nlp_solver_type not in ("SQP_RTI", "SQP"):
+            raise ValueError(f"nlp_solver_type {o.nlp_solver_type!r}")
+        dt = o.tf / N
+        lbx = np.full((N + 1, NX), -INF)
+        ubx = np.full((N + 1, NX), INF)
+        idx = np.asarray(c.idxbx, dtype=int)
+        lbx[1:N, idx] = np.asarray(c.lbx, dtype=float)
+        ubx[1:N, idx] = np.asarray(c.ubx, dtype=float)
+        idxe = np.asarray(c.idxbx_e, dtype=int)
+        lbx[N, idxe] = np.asarray(c.lbx_e, dtype=float)
+        ubx[N, idxe] = np.asarray(c.ubx_e, dtype=float)
+        lbu = np.full((N, NU), -INF)
+        ubu = np.full((N, NU), INF)
+        idu = np.asarray(c.idxbu, dtype=int)
+        lbu[:, idu] = np.asarray(c.lbu, dtype=float)
+        ubu[:, idu] = np.asarray(c.ubu, dtype=float)
+        ng = np.asarray(c.C).shape[0]
+        if ng > NG:
+            raise ValueError(f"at most {NG} general constraint rows")
+        Cm = np.zeros((NG, NX)); Dm = np.zeros((NG, NU)); lg = np.full(NG, -INF); ug = np.full(NG, INF)
+        Cm[:ng] = c.C; Dm[:ng] = c.D; lg[:ng] = c.lg; ug[:ng] = c.ug
+        return OcpData(
+            N=N, M=int(o.sim_method_num_steps), dt=dt, model=ocp.model.model_id,
+            integrator=INTEG_RK4,
+            cost_scale_stage=dt if o.cost_scale_stage is None else float(o.cost_scale_stage),
+            W=np.tile(np.asarray(ocp.cost.W, dtype=float)[None], (N, 1, 1)), W_e=np.array(ocp.cost.W_e, dtype=float),
+            lbx=lbx, ubx=ubx, lbu=lbu, ubu=ubu,
+            C=np.tile(Cm[None], (N, 1, 1)), D=np.tile(Dm[None], (N, 1, 1)),
+            lg=np.tile(lg[None], (N, 1)), ug=np.tile(ug[None], (N, 1)),
+            ipm_iter_max=int(o.qp_solver_iter_max), ipm_tol=float(o.qp_tol), ipm_mu0=float(o.qp_mu0),
+            ipm_tau0=float(o.qp_tau0), nlp_solver_type=o.nlp_solver_type,
+            nlp_solver_max_iter=int(o.nlp_solver_max_iter), nlp_tol=float(o.nlp_tol),
+        )
+
+    def as_dict(self, s_ref, kappa_ref) -> dict:
+        """Plain description (arrays + scalars) incl. the track tables; what tests hand to the oracle."""
+        d = {k: getattr(self, k) for k in (
+            "N", "M", "dt", "model", "integrator", "cost_scale_stage", "W", "W_e", "lbx", "ubx", "lbu", "ubu",
+            "C", "D", "lg", "ug", "ipm_iter_max", "ipm_tol", "ipm_mu0", "ipm_tau0")}
+        d["s_ref"] = np.atleast_2d(np.asarray(s_ref, dtype=float))
+        d["kappa_ref"] = np.atleast_2d(np.asarray(kappa_ref, dtype=float))
+        return d
+
+
+def default_weights(
+    q_s=1.0, q_n=1.0, q_psi=1.0, q_v_x=1.0, q_v_y=1.0, q_r=1.0, q_T=1.0, q_delta=100.0,
+    q_s_f=1000.0, q_n_f=100.0, q_psi_f=100.0, q_v_x_f=1.0, q_v_y_f=1.0, q_r_f=1.0, q_T_f=1.0, q_delta_f=100.0,
+    q_T_dot=0.0, q_delta_dot=500.0,
+):
+    """Stage and terminal weight matrices of ``IHM2Controller.__init__`` (``python/main.py:193-210,255-295``)."""
+    W = np.diag([q_s, q_n, q_psi, q_v_x, q_v_y, q_r, q_T, q_delta, q_T, q_delta, q_T_dot, q_delta_dot])
+    W_e = np.diag([q_s_f, q_n_f, q_psi_f, q_v_x_f, q_v_y_f, q_r_f, q_T_f, q_delta_f])
+    return W, W_e

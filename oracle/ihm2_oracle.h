@@ -1,0 +1,135 @@
+/*
+ * ihm2_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C, double-precision, readable restatement of the reference's NMPC hot path
+ * (tudoroancea/ihm2: python/models.py, python/mpc.py, python/main.py) plus the
+ * SQP-RTI arithmetic that the reference delegates to acados/HPIPM (third party,
+ * unpinned, absent from the reference tree -- see SURVEY.md F1/F2).
+ *
+ * PARITY UNPINNED: the reference holds no tests, golden vectors or fixtures for this
+ * path and acados/casadi cannot be imported here, so this oracle is pinned only by
+ * (i) the golden constants imported from python/constants.py (tests/golden/constants.json)
+ * and (ii) self-certifying checks (complex-step Jacobians, high-accuracy ODE reference,
+ * finite-difference sensitivities, KKT residuals, scipy cross-checks) in tests/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this
+ * library. The product (ihm2_amd/) never links, imports or calls it.
+ *
+ * Conventions: x = (s, n, psi, v_x, v_y, r, T, delta), u = (u_T, u_delta)
+ * (python/models.py:236-245). All arrays are C-contiguous doubles.
+ */
+#ifndef IHM2_ORACLE_H
+#define IHM2_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NX 8
+#define ORC_NU 2
+#define ORC_NZ 10
+#define ORC_NY 12
+#define ORC_NYE 8
+#define ORC_NG 2
+/* one-sided inequalities per stage: lower (8 bx, 2 bu, 2 g) then upper (8, 2, 2) */
+#define ORC_NC 12
+#define ORC_NMAX 128
+
+enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1 };
+enum { ORC_INTEG_RK4 = 0 };
+
+typedef struct {
+    int N;       /* shooting intervals */
+    int M;       /* RK4 sub-steps per interval */
+    int model;   /* ORC_MODEL_* */
+    int integrator; /* ORC_INTEG_* */
+    double dt;   /* interval length */
+    double cost_scale_stage; /* factor on stage cost terms k<N (acados: time step) */
+    /* track tables: ntracks x (s_ref[nknots], kappa_ref[nknots]) */
+    int ntracks;
+    int nknots;
+    const double *s_ref;     /* (ntracks, nknots) */
+    const double *kappa_ref; /* (ntracks, nknots) */
+    /* cost, shared by the batch */
+    const double *W;   /* (N, 12, 12) */
+    const double *W_e; /* (8, 8) */
+    /* bounds, shared by the batch; +-inf (|v| >= 1e20) = absent */
+    const double *lbx; /* (N+1, 8) ; stage 0 row ignored (x_0 is fixed to x0) */
+    const double *ubx; /* (N+1, 8) */
+    const double *lbu; /* (N, 2) */
+    const double *ubu; /* (N, 2) */
+    const double *C;   /* (N, 2, 8) */
+    const double *D;   /* (N, 2, 2) */
+    const double *lg;  /* (N, 2) */
+    const double *ug;  /* (N, 2) */
+    /* interior-point options */
+    int ipm_iter_max;
+    double ipm_tol;  /* abs inf-norm tolerance on all four residual groups */
+    double ipm_mu0;
+    double ipm_tau0; /* lower clamp for initial slacks */
+} orc_problem;
+
+/* --- model (python/models.py:232-307 fkin6, :455-606 fdyn6) --- */
+double orc_kappa(const double *s_ref, const double *kappa_ref, int nknots, double s, double *dkappa_ds);
+void orc_f(int model, const double *x, const double *u, const double *s_ref, const double *kappa_ref,
+           int nknots, double *xdot);
+/* J is 8x10 row-major: d xdot / d (x, u) */
+void orc_jac(int model, const double *x, const double *u, const double *s_ref, const double *kappa_ref,
+             int nknots, double *xdot, double *J);
+/* same Jacobian by complex-step evaluation of the model formulas (both models) */
+void orc_jac_cs(int model, const double *x, const double *u, const double *s_ref, const double *kappa_ref,
+                int nknots, double *xdot, double *J);
+
+/* --- integrator: RK4 x M with forward sensitivities; A 8x8, Bm 8x2 row-major --- */
+void orc_rk4_sens(int model, int integrator, const double *x, const double *u, const double *s_ref,
+                  const double *kappa_ref, int nknots, double dt, int M, double *xnext, double *A,
+                  double *Bm);
+void orc_rk4(int model, int integrator, const double *x, const double *u, const double *s_ref,
+             const double *kappa_ref, int nknots, double dt, int M, double *xnext);
+
+/* --- stage-wise QP by Riccati-based primal-dual interior point ---
+ * H (N+1,10,10), g (N+1,10), A (N,8,8), Bm (N,8,2), b (N,8), dx0 (8),
+ * R (N+1, 12, 10) constraint rows, dl/du (N+1, 12) (+-inf = absent)
+ * out: dz (N+1,10), pi (N+1,8), lam (N+1,24) [12 lower then 12 upper], t (N+1,24)
+ * stats[0..3] = res_g,res_b,res_d,res_m at exit, stats[4]=mu, stats[5..6] = scales sg, sb (stats has 8 slots)
+ * tolerances are relative: res_g,res_m <= tol*sg, res_b,res_d <= tol*sb; mu0 is a factor on sg.
+ * returns 0 converged, 1 max-iter but within 1e4*tol, 2 min step, 3 NaN, 4 max-iter and not converged */
+int orc_qp_solve(int N, const double *H, const double *g, const double *A, const double *Bm,
+                 const double *b, const double *dx0, const double *R, const double *dl,
+                 const double *du, int iter_max, double tol, double mu0, double tau0, double *dz,
+                 double *pi, double *lam, double *t, double *stats, int *iters);
+
+/* --- one SQP-RTI iteration for a batch (OpenMP over instances) ---
+ * x (B,N+1,8), u (B,N,2), x0 (B,8), yref (B,N,12), yref_e (B,8), track_id (B)
+ * pi (B,N+1,8), lam (B,N+1,24): multipliers, in/out
+ * status (B) int32: 0 ok, 1 NaN, 4 QP failure (acados codes, dpc/main.py:287-293); a failed
+ * instance keeps its iterate and multipliers unchanged
+ * res (B,4): NLP KKT residual inf-norms (stat, eq, ineq, comp) at the iterate BEFORE the step
+ * qp_iter (B) */
+void orc_rti_step(const orc_problem *P, int B, double *x, double *u, const double *x0,
+                  const double *yref, const double *yref_e, const int *track_id, double *pi,
+                  double *lam, int *status, double *res, int *qp_iter, int nthreads);
+
+/* linearisation only: A (B,N,8,8), Bm (B,N,8,2), b (B,N,8) where b = Phi(x_k,u_k) - x_{k+1} */
+void orc_linearize(const orc_problem *P, int B, const double *x, const double *u,
+                   const int *track_id, double *A, double *Bm, double *b, int nthreads);
+
+/* QP data of one instance as the RTI step assembles it (for QP-level parity tests) */
+void orc_build_qp(const orc_problem *P, const double *x, const double *u, const double *x0,
+                  const double *yref, const double *yref_e, int track_id, double *H, double *g,
+                  double *A, double *Bm, double *b, double *dx0, double *R, double *dl, double *du);
+
+/* warm-start shift + reference ramp of IHM2Controller.compute_control (python/main.py:297-322) */
+void orc_prepare_step(int N, int B, const double *x0, double s_target, double *x, double *u,
+                      double *yref, double *yref_e);
+
+/* plant step for closed-loop (python/main.py:476-502): RK4 x M on the chosen model */
+void orc_sim_step(const orc_problem *P, int B, int model, int M, const double *x, const double *u,
+                  const int *track_id, double *xnext, int nthreads);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,195 @@
+"""CPU ORACLE binding (test infrastructure, NOT the product).
+
+ctypes wrapper over ``oracle/libihm2_oracle.so`` (built by ``make -C oracle``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libihm2_oracle.so")
+NX, NU, NZ, NY, NC, NG = 8, 2, 10, 12, 12, 2
+MODEL_FKIN6, MODEL_FDYN6 = 0, 1
+INTEG_RK4 = 0
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class _Problem(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("M", C.c_int), ("model", C.c_int), ("integrator", C.c_int),
+        ("dt", C.c_double), ("cost_scale_stage", C.c_double),
+        ("ntracks", C.c_int), ("nknots", C.c_int), ("s_ref", _dp), ("kappa_ref", _dp),
+        ("W", _dp), ("W_e", _dp), ("lbx", _dp), ("ubx", _dp), ("lbu", _dp), ("ubu", _dp),
+        ("C", _dp), ("D", _dp), ("lg", _dp), ("ug", _dp),
+        ("ipm_iter_max", C.c_int), ("ipm_tol", C.c_double), ("ipm_mu0", C.c_double), ("ipm_tau0", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_kappa.restype = C.c_double
+        _lib.orc_qp_solve.restype = C.c_int
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+def f(model, x, u, s_ref, kappa_ref):
+    x, xp = _d(x); u, up = _d(u); s, sp = _d(s_ref); k, kp = _d(kappa_ref)
+    out = np.zeros(NX)
+    lib().orc_f(C.c_int(model), xp, up, sp, kp, C.c_int(len(s)), out.ctypes.data_as(_dp))
+    return out
+
+
+def jac(model, x, u, s_ref, kappa_ref, complex_step=False):
+    x, xp = _d(x); u, up = _d(u); s, sp = _d(s_ref); k, kp = _d(kappa_ref)
+    out = np.zeros(NX); J = np.zeros((NX, NZ))
+    fn = lib().orc_jac_cs if complex_step else lib().orc_jac
+    fn(C.c_int(model), xp, up, sp, kp, C.c_int(len(s)), out.ctypes.data_as(_dp), J.ctypes.data_as(_dp))
+    return out, J
+
+
+def kappa(s_ref, kappa_ref, s):
+    sr, sp = _d(s_ref); k, kp = _d(kappa_ref)
+    dk = C.c_double(0.0)
+    v = lib().orc_kappa(sp, kp, C.c_int(len(sr)), C.c_double(s), C.byref(dk))
+    return v, dk.value
+
+
+def rk4_sens(model, x, u, s_ref, kappa_ref, dt, M, integrator=INTEG_RK4):
+    x, xp = _d(x); u, up = _d(u); s, sp = _d(s_ref); k, kp = _d(kappa_ref)
+    xn = np.zeros(NX); A = np.zeros((NX, NX)); Bm = np.zeros((NX, NU))
+    lib().orc_rk4_sens(C.c_int(model), C.c_int(integrator), xp, up, sp, kp, C.c_int(len(s)), C.c_double(dt), C.c_int(M),
+                       xn.ctypes.data_as(_dp), A.ctypes.data_as(_dp), Bm.ctypes.data_as(_dp))
+    return xn, A, Bm
+
+
+def rk4(model, x, u, s_ref, kappa_ref, dt, M, integrator=INTEG_RK4):
+    x, xp = _d(x); u, up = _d(u); s, sp = _d(s_ref); k, kp = _d(kappa_ref)
+    xn = np.zeros(NX)
+    lib().orc_rk4(C.c_int(model), C.c_int(integrator), xp, up, sp, kp, C.c_int(len(s)), C.c_double(dt), C.c_int(M),
+                  xn.ctypes.data_as(_dp))
+    return xn
+
+
+def qp_solve(H, g, A, Bm, b, dx0, R, dl, du, iter_max=50, tol=1e-6, mu0=0.03, tau0=0.1):
+    N = A.shape[0]
+    H, Hp = _d(H); g, gp = _d(g); A, Ap = _d(A); Bm, Bp = _d(Bm); b, bp = _d(b); dx0, xp = _d(dx0)
+    R, Rp = _d(R); dl, lp = _d(dl); du, up = _d(du)
+    dz = np.zeros((N + 1, NZ)); pi = np.zeros((N + 1, NX)); lam = np.zeros((N + 1, 2 * NC)); t = np.zeros((N + 1, 2 * NC))
+    stats = np.zeros(8); iters = C.c_int(0)
+    st = lib().orc_qp_solve(C.c_int(N), Hp, gp, Ap, Bp, bp, xp, Rp, lp, up, C.c_int(iter_max), C.c_double(tol),
+                            C.c_double(mu0), C.c_double(tau0), dz.ctypes.data_as(_dp), pi.ctypes.data_as(_dp),
+                            lam.ctypes.data_as(_dp), t.ctypes.data_as(_dp), stats.ctypes.data_as(_dp), C.byref(iters))
+    return dict(status=st, dz=dz, pi=pi, lam=lam, t=t, stats=stats, iters=iters.value)
+
+
+class OracleProblem:
+    """Holds the arrays of an ``orc_problem`` alive.  ``desc`` is a plain dict of numpy arrays and
+    scalars (the product's ``OcpData.as_dict()`` produces exactly this)."""
+
+    def __init__(self, desc: dict):
+        self.N = int(desc["N"]); self.M = int(desc["M"])
+        self._keep = {}
+        p = _Problem()
+        p.N = self.N; p.M = self.M; p.model = int(desc.get("model", 0)); p.integrator = int(desc.get("integrator", 0))
+        p.dt = float(desc["dt"]); p.cost_scale_stage = float(desc["cost_scale_stage"])
+        s_ref = np.atleast_2d(np.asarray(desc["s_ref"], dtype=np.float64))
+        k_ref = np.atleast_2d(np.asarray(desc["kappa_ref"], dtype=np.float64))
+        p.ntracks, p.nknots = s_ref.shape
+        for name, arr in (("s_ref", s_ref), ("kappa_ref", k_ref), ("W", desc["W"]), ("W_e", desc["W_e"]),
+                          ("lbx", desc["lbx"]), ("ubx", desc["ubx"]), ("lbu", desc["lbu"]), ("ubu", desc["ubu"]),
+                          ("C", desc["C"]), ("D", desc["D"]), ("lg", desc["lg"]), ("ug", desc["ug"])):
+            a, ptr = _d(arr)
+            self._keep[name] = a
+            setattr(p, name, ptr)
+        N = self.N
+        assert self._keep["W"].shape == (N, NY, NY) and self._keep["lbx"].shape == (N + 1, NX)
+        assert self._keep["C"].shape == (N, NG, NX) and self._keep["D"].shape == (N, NG, NU)
+        p.ipm_iter_max = int(desc["ipm_iter_max"]); p.ipm_tol = float(desc["ipm_tol"])
+        p.ipm_mu0 = float(desc["ipm_mu0"]); p.ipm_tau0 = float(desc["ipm_tau0"])
+        self.p = p
+
+    def rti_step(self, x, u, x0, yref, yref_e, track_id=None, pi=None, lam=None, nthreads=0):
+        """One RTI iteration; ``x`` (B,N+1,8) and ``u`` (B,N,2) are updated IN PLACE."""
+        N = self.N
+        assert x.dtype == np.float64 and x.flags.c_contiguous and u.dtype == np.float64 and u.flags.c_contiguous
+        B = x.shape[0]
+        x0, x0p = _d(x0); yref, yp = _d(yref); yref_e, yep = _d(yref_e)
+        tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
+        if pi is None: pi = np.zeros((B, N + 1, NX))
+        if lam is None: lam = np.zeros((B, N + 1, 2 * NC))
+        assert pi.flags.c_contiguous and lam.flags.c_contiguous
+        status = np.zeros(B, dtype=np.int32); res = np.zeros((B, 4)); qp_iter = np.zeros(B, dtype=np.int32)
+        lib().orc_rti_step(C.byref(self.p), C.c_int(B), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp), x0p, yp, yep, tp,
+                           pi.ctypes.data_as(_dp), lam.ctypes.data_as(_dp), status.ctypes.data_as(_ip),
+                           res.ctypes.data_as(_dp), qp_iter.ctypes.data_as(_ip), C.c_int(nthreads))
+        return dict(status=status, res=res, qp_iter=qp_iter, pi=pi, lam=lam)
+
+    def linearize(self, x, u, track_id=None, nthreads=0):
+        N = self.N; B = x.shape[0]
+        x, xp = _d(x); u, up = _d(u)
+        tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
+        A = np.zeros((B, N, NX, NX)); Bm = np.zeros((B, N, NX, NU)); b = np.zeros((B, N, NX))
+        lib().orc_linearize(C.byref(self.p), C.c_int(B), xp, up, tp, A.ctypes.data_as(_dp), Bm.ctypes.data_as(_dp),
+                            b.ctypes.data_as(_dp), C.c_int(nthreads))
+        return A, Bm, b
+
+    def build_qp(self, x, u, x0, yref, yref_e, track_id=0):
+        N = self.N
+        x, xp = _d(x); u, up = _d(u); x0, x0p = _d(x0); yref, yp = _d(yref); yref_e, yep = _d(yref_e)
+        H = np.zeros((N + 1, NZ, NZ)); g = np.zeros((N + 1, NZ)); A = np.zeros((N, NX, NX)); Bm = np.zeros((N, NX, NU))
+        b = np.zeros((N, NX)); dx0 = np.zeros(NX); R = np.zeros((N + 1, NC, NZ)); dl = np.zeros((N + 1, NC)); du = np.zeros((N + 1, NC))
+        lib().orc_build_qp(C.byref(self.p), xp, up, x0p, yp, yep, C.c_int(track_id), *[a.ctypes.data_as(_dp) for a in (H, g, A, Bm, b, dx0, R, dl, du)])
+        return dict(H=H, g=g, A=A, Bm=Bm, b=b, dx0=dx0, R=R, dl=dl, du=du)
+
+    def sim_step(self, x, u, model, M, track_id=None, nthreads=0):
+        B = x.shape[0]
+        x, xp = _d(x); u, up = _d(u)
+        tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
+        xn = np.zeros((B, NX))
+        lib().orc_sim_step(C.byref(self.p), C.c_int(B), C.c_int(model), C.c_int(M), xp, up, tp, xn.ctypes.data_as(_dp), C.c_int(nthreads))
+        return xn
+
+
+def prepare_step(N, x0, s_target, x, u):
+    """Shift + reference ramp in place on x (B,N+1,8), u (B,N,2); returns yref (B,N,12), yref_e (B,8)."""
+    B = x.shape[0]
+    assert x.flags.c_contiguous and u.flags.c_contiguous
+    x0, x0p = _d(x0)
+    yref = np.zeros((B, N, NY)); yref_e = np.zeros((B, NX))
+    lib().orc_prepare_step(C.c_int(N), C.c_int(B), x0p, C.c_double(s_target), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp),
+                           yref.ctypes.data_as(_dp), yref_e.ctypes.data_as(_dp))
+    return yref, yref_e
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
