@@ -1,0 +1,188 @@
+// kernels_linearize.hip -- HOT LOOP 1 of the RTI step: for every (instance b, shooting interval k)
+// integrate the model over dt with M classical RK4 sub-steps and propagate the forward sensitivities
+// S = d x_m / d (x_k, u_k) through the same stages (exact derivative of the discrete map).
+//
+// Replaces what acados' ERK integrator does inside AcadosOcpSolver.solve() for the reference
+// (python/main.py:325; options old/generate.py:23-25 with sim_method_num_steps = M).
+// RK4 tableau as dpc/main.py:87-97.
+//
+// Mapping: one lane per (b, k) pair, b fastest, so a wavefront covers 64 consecutive instances of one
+// interval and every global access is one coalesced 512-byte row of the SoA arrays.
+// Sensitivities are held column-wise in registers; only the 52 structurally non-zero entries of the
+// 8x10 matrix are stored and only the 31 non-zeros of the model Jacobian are multiplied
+// (model.hpp: JX_MASK / S_COL_MASK).  Algorithmic traffic per pair: read 10 + 8 doubles, write 88.
+#include "ihm2mpc_internal.h"
+#include "model.hpp"
+
+using namespace ihm2;
+
+namespace {
+
+// one RK4 stage of sensitivity column COL:  dX = S + ah*dK_prev ; dK = Jx dX + Ju[:,COL] ; Sacc += wh*dK
+template <int COL>
+__device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const double (&S)[8], double (&Sacc)[8],
+                                               double (&dK)[8], double ah, double wh)
+{
+    constexpr unsigned cm = S_COL_MASK[COL];
+    double dX[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++)
+        if ((cm >> l) & 1u) dX[l] = fma(ah, dK[l], S[l]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (!((cm >> i) & 1u)) continue;
+        double acc = 0.0;
+        if (COL >= 8 && ((JU_MASK[i] >> (COL - 8)) & 1u)) acc = J[i][COL];
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+            if (((JX_MASK[i] & cm) >> l) & 1u) acc = fma(J[i][l], dX[l], acc);
+        dK[i] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((cm >> i) & 1u) Sacc[i] = fma(wh, dK[i], Sacc[i]);
+}
+
+template <int COL>
+__device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&dst)[8])
+{
+    constexpr unsigned cm = S_COL_MASK[COL];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((cm >> i) & 1u) dst[i] = src[i];
+}
+
+#define FOR_ALL_COLS(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9)
+
+__global__ __launch_bounds__(64) void k_linearize_fkin6(
+    int B, int Bp, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
+    const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *__restrict__ xs,
+    const double *__restrict__ us, double *__restrict__ Aout, double *__restrict__ Bout, double *__restrict__ bout)
+{
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    const int b = (int)(t % Bp);
+    const int k = (int)(t / Bp);
+    if (k >= N || b >= B) return;
+
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)(k * 8 + i) * Bp + b];
+    const double u_T = us[(size_t)(k * 2 + 0) * Bp + b];
+    const double u_d = us[(size_t)(k * 2 + 1) * Bp + b];
+    const int tid = track_id[b];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
+
+    // S, Sacc, dK: [column][row]; only rows in S_COL_MASK[column] are ever touched
+    double S[10][8], Sacc[10][8], dK[10][8];
+#pragma unroll
+    for (int c = 0; c < 10; c++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { S[c][i] = (c == i) ? 1.0 : 0.0; dK[c][i] = 0.0; }
+
+    const double h = dt / M;
+    for (int m = 0; m < M; m++) {
+        double xacc[8], K[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+#define COPY_S_TO_ACC(c) sens_col_copy<c>(S[c], Sacc[c]);
+        FOR_ALL_COLS(COPY_S_TO_ACC)
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+            double X[8], J[8][10];
+#pragma unroll
+            for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+            fkin6_eval<true>(X, u_T, u_d, trk, K, J);
+#pragma unroll
+            for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+#define STAGE_COL(c) sens_col_stage<c>(J, S[c], Sacc[c], dK[c], ah, wh);
+            FOR_ALL_COLS(STAGE_COL)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = xacc[i];
+#define COPY_ACC_TO_S(c) sens_col_copy<c>(Sacc[c], S[c]);
+        FOR_ALL_COLS(COPY_ACC_TO_S)
+    }
+
+    // outputs: A (8x8 row-major), Bm (8x2), b = Phi(x_k,u_k) - x_{k+1}
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const double v = ((S_COL_MASK[j] >> i) & 1u) ? S[j][i] : 0.0;
+            Aout[(size_t)((k * 8 + i) * 8 + j) * Bp + b] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const double v = ((S_COL_MASK[8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
+            Bout[(size_t)((k * 8 + i) * 2 + j) * Bp + b] = v;
+        }
+        bout[(size_t)(k * 8 + i) * Bp + b] = x[i] - xs[(size_t)((k + 1) * 8 + i) * Bp + b];
+    }
+}
+
+// plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 = kin/dyn switch of
+// python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic)
+__global__ __launch_bounds__(64) void k_sim_step(int B, int Bp, int model, int M, double dt, int nknots,
+                                                 const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
+                                                 const int32_t *__restrict__ track_id, const double *xs,
+                                                 const double *__restrict__ us, double *xn)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)i * Bp + b];
+    const double u_T = us[b], u_d = us[(size_t)Bp + b];
+    const int tid = track_id[b];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
+    int mdl = model;
+    if (model < 0) {
+        const double beta = atan(k_rwd * tan(x[7]));
+        const double v2 = x[3] * x[3] + x[4] * x[4];
+        mdl = (v2 * sin(beta) / k_lR <= 3.0) ? IHM2MPC_MODEL_FKIN6 : IHM2MPC_MODEL_FDYN6;
+    }
+    const double h = dt / M;
+    double J[8][10];
+    for (int m = 0; m < M; m++) {
+        double xacc[8], K[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+            double X[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+            if (mdl == IHM2MPC_MODEL_FKIN6) fkin6_eval<false>(X, u_T, u_d, trk, K, J);
+            else fdyn6_eval(X, u_T, u_d, trk, K);
+#pragma unroll
+            for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = xacc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) xn[(size_t)i * Bp + b] = x[i];
+}
+
+}  // namespace
+
+void ihm2_launch_linearize(ihm2mpc_handle *h)
+{
+    const long total = (long)h->Bp * h->N;
+    const int blocks = (int)((total + 63) / 64);
+    hipLaunchKernelGGL(k_linearize_fkin6, dim3(blocks), dim3(64), 0, h->stream, h->B, h->Bp, h->N, h->cfg.M, h->cfg.dt,
+                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->A, h->Bm, h->bvec);
+}
+
+void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x_soa, const double *u_soa, double *xn_soa)
+{
+    const int blocks = (h->B + 63) / 64;
+    hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, h->stream, h->B, h->Bp, model, M_sim, h->cfg.dt,
+                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x_soa, u_soa, xn_soa);
+}

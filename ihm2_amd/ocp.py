@@ -300,7 +300,7 @@ class OcpData:
         )
 
     def as_dict(self, s_ref, kappa_ref) -> dict:
-        """Plain description (arrays + scalars) incl. the track tables; what tests hand to the oracle."""
+        """Plain description (arrays + scalars) incl. the track tables (used by the test suite to describe the same problem to its CPU checker)."""
         d = {k: getattr(self, k) for k in (
             "N", "M", "dt", "model", "integrator", "cost_scale_stage", "W", "W_e", "lbx", "ubx", "lbu", "ubu",
             "C", "D", "lg", "ug", "ipm_iter_max", "ipm_tol", "ipm_mu0", "ipm_tau0")}

@@ -1,0 +1,360 @@
+"""Batched NMPC solver on MI355X behind the reference's ``AcadosOcpSolver`` call surface.
+
+Reference call sites this mirrors (tudoroancea/ihm2):
+  * construction ``AcadosOcpSolver(ocp, json_file=..., verbose=False)`` -- ``python/mpc.py:104-113``
+  * ``solver.set(stage, field, value)`` with fields ``"p","lbx","ubx","yref","x","u"``
+    -- ``python/main.py:252,299-322``
+  * ``solver.cost_set(stage, "W", W[, api="new"])`` -- ``python/main.py:253-295``, ``dpc/main.py:263-281``
+  * ``solver.constraints_set(stage, "lbx"/"ubx"/"C"..., v)`` -- ``dpc/main.py:226-227,259-261``
+  * ``status = solver.solve()`` -- ``python/main.py:325``; status codes ``dpc/main.py:287-293``
+  * ``solver.get(stage, "x"/"u")`` -- ``python/main.py:331-334``
+
+Two layers: :class:`BatchedOcpSolver` owns one ``ihm2mpc`` handle (B instances on one GPU) and speaks
+``(B, ...)`` C-contiguous float64 arrays; :class:`AcadosOcpSolver` is the per-instance shim
+(``view = batch[i]``, or a batch of one when built from an OCP like the reference does).
+Host code is NumPy + ctypes only; all arithmetic runs in ``libihm2mpc.so`` (HIP, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .constants import NG, NU, NX, NY
+from .ocp import AcadosOcp, AcadosOcpOptions, OcpData
+
+NLAM = 24
+_SOLVER_TYPE = {"SQP_RTI": 0, "SQP": 1}
+
+
+def _f64(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_lib.c_double_p)
+
+
+class BatchedOcpSolver:
+    """B independent instances of the bicycle NMPC on one MI355X."""
+
+    def __init__(self, ocp: AcadosOcp, batch_size: int, s_ref, kappa_ref, track_id=None, device: int = 0):
+        self.lib = _lib.load()
+        self.ocp = ocp
+        self.data: OcpData = ocp.flatten()
+        d = self.data
+        self.B, self.N = int(batch_size), d.N
+        s_ref = np.atleast_2d(_f64(s_ref)); kappa_ref = np.atleast_2d(_f64(kappa_ref))
+        if s_ref.shape != kappa_ref.shape:
+            raise ValueError("s_ref and kappa_ref must have the same shape (ntracks, nknots)")
+        self.ntracks, self.nknots = s_ref.shape
+        cfg = _lib.Config(
+            batch=self.B, N=d.N, M=d.M, model=d.model, ntracks=self.ntracks, nknots=self.nknots, device=device,
+            nlp_solver_type=_SOLVER_TYPE[d.nlp_solver_type], nlp_solver_max_iter=d.nlp_solver_max_iter,
+            ipm_iter_max=d.ipm_iter_max, dt=d.dt, cost_scale_stage=d.cost_scale_stage, ipm_tol=d.ipm_tol,
+            ipm_mu0=d.ipm_mu0, ipm_tau0=d.ipm_tau0, nlp_tol=d.nlp_tol)
+        self._h = C.c_void_p()
+        _lib.check(self.lib.ihm2mpc_create(C.byref(cfg), C.byref(self._h)))
+        self._s_ref, self._kappa_ref = s_ref.copy(), kappa_ref.copy()
+        self._push_tracks()
+        self.set_track_id(np.zeros(self.B, dtype=np.int32) if track_id is None else track_id)
+        self._push_weights()
+        self._push_bounds()
+
+    # ---- lifetime ----
+    def free(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ihm2mpc_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.B
+
+    def __getitem__(self, i: int) -> "AcadosOcpSolver":
+        if not -self.B <= i < self.B:
+            raise IndexError(i)
+        return AcadosOcpSolver._view(self, i % self.B)
+
+    # ---- shared problem data ----
+    def _push_tracks(self):
+        _lib.check(self.lib.ihm2mpc_set_tracks(self._h, _ptr(self._s_ref), _ptr(self._kappa_ref)))
+
+    def _push_weights(self):
+        d = self.data
+        d.W = _f64(d.W, (self.N, NY, NY), "W"); d.W_e = _f64(d.W_e, (NX, NX), "W_e")
+        _lib.check(self.lib.ihm2mpc_set_weights(self._h, _ptr(d.W), _ptr(d.W_e)))
+
+    def _push_bounds(self):
+        d = self.data
+        arrs = [_f64(getattr(d, n)) for n in ("lbx", "ubx", "lbu", "ubu", "C", "D", "lg", "ug")]
+        _lib.check(self.lib.ihm2mpc_set_bounds(self._h, *[_ptr(a) for a in arrs]))
+
+    def set_tracks(self, s_ref, kappa_ref):
+        self._s_ref = _f64(np.atleast_2d(s_ref), (self.ntracks, self.nknots), "s_ref")
+        self._kappa_ref = _f64(np.atleast_2d(kappa_ref), (self.ntracks, self.nknots), "kappa_ref")
+        self._push_tracks()
+
+    def set_track_id(self, track_id):
+        tid = np.ascontiguousarray(track_id, dtype=np.int32)
+        if tid.shape != (self.B,):
+            raise ValueError(f"track_id must have shape ({self.B},)")
+        self._track_id = tid
+        _lib.check(self.lib.ihm2mpc_set_track_id(self._h, tid.ctypes.data_as(_lib.c_int32_p)))
+
+    def set_weights(self, W=None, W_e=None):
+        """W: (12,12) for all stages or (N,12,12); W_e: (8,8).  Shared by the batch."""
+        if W is not None:
+            W = np.asarray(W, dtype=np.float64)
+            self.data.W = np.tile(W[None], (self.N, 1, 1)) if W.ndim == 2 else W
+        if W_e is not None:
+            self.data.W_e = np.asarray(W_e, dtype=np.float64)
+        self._push_weights()
+
+    # ---- per-instance data, batched ----
+    def set_x0(self, x0):
+        _lib.check(self.lib.ihm2mpc_set_x0(self._h, _ptr(_f64(x0, (self.B, NX), "x0"))))
+
+    def set_x(self, x):
+        _lib.check(self.lib.ihm2mpc_set_x(self._h, _ptr(_f64(x, (self.B, self.N + 1, NX), "x"))))
+
+    def set_u(self, u):
+        _lib.check(self.lib.ihm2mpc_set_u(self._h, _ptr(_f64(u, (self.B, self.N, NU), "u"))))
+
+    def set_yref(self, yref):
+        _lib.check(self.lib.ihm2mpc_set_yref(self._h, _ptr(_f64(yref, (self.B, self.N, NY), "yref"))))
+
+    def set_yref_e(self, yref_e):
+        _lib.check(self.lib.ihm2mpc_set_yref_e(self._h, _ptr(_f64(yref_e, (self.B, NX), "yref_e"))))
+
+    def set_multipliers(self, pi=None, lam=None):
+        pi_a = None if pi is None else _f64(pi, (self.B, self.N + 1, NX), "pi")
+        lam_a = None if lam is None else _f64(lam, (self.B, self.N + 1, NLAM), "lam")
+        _lib.check(self.lib.ihm2mpc_set_multipliers(self._h, None if pi_a is None else _ptr(pi_a),
+                                                    None if lam_a is None else _ptr(lam_a)))
+
+    # ---- the hot path ----
+    def init_guess(self, v_ref_scale: float = 1.0):
+        _lib.check(self.lib.ihm2mpc_init_guess(self._h, float(v_ref_scale)))
+
+    def prepare_step(self, s_target: float):
+        """Reference ramp + warm-start shift of ``compute_control`` (``python/main.py:303-322``) on device."""
+        _lib.check(self.lib.ihm2mpc_prepare_step(self._h, float(s_target)))
+
+    def solve_async(self, n_iter: int = 0):
+        _lib.check(self.lib.ihm2mpc_solve(self._h, int(n_iter)))
+
+    def solve(self, n_iter: int = 0) -> np.ndarray:
+        """Runs the RTI iteration(s); returns the per-instance acados status codes, int32[B]."""
+        self.solve_async(n_iter)
+        return self.get_status()
+
+    def synchronize(self):
+        _lib.check(self.lib.ihm2mpc_synchronize(self._h))
+
+    def linearize(self):
+        _lib.check(self.lib.ihm2mpc_linearize(self._h))
+
+    def get_linearization(self):
+        A = np.empty((self.B, self.N, NX, NX)); Bm = np.empty((self.B, self.N, NX, NU)); b = np.empty((self.B, self.N, NX))
+        _lib.check(self.lib.ihm2mpc_get_linearization(self._h, _ptr(A), _ptr(Bm), _ptr(b)))
+        return A, Bm, b
+
+    def _get(self, fn, shape):
+        out = np.empty(shape, dtype=np.float64)
+        _lib.check(fn(self._h, _ptr(out)))
+        return out
+
+    def get_x(self):
+        return self._get(self.lib.ihm2mpc_get_x, (self.B, self.N + 1, NX))
+
+    def get_u(self):
+        return self._get(self.lib.ihm2mpc_get_u, (self.B, self.N, NU))
+
+    def get_u0(self):
+        return self._get(self.lib.ihm2mpc_get_u0, (self.B, NU))
+
+    def get_x0(self):
+        return self._get(self.lib.ihm2mpc_get_x0, (self.B, NX))
+
+    def get_residuals(self):
+        return self._get(self.lib.ihm2mpc_get_residuals, (self.B, 4))
+
+    def get_multipliers(self):
+        pi = np.empty((self.B, self.N + 1, NX)); lam = np.empty((self.B, self.N + 1, NLAM))
+        _lib.check(self.lib.ihm2mpc_get_multipliers(self._h, _ptr(pi), _ptr(lam)))
+        return pi, lam
+
+    def get_status(self):
+        out = np.empty(self.B, dtype=np.int32)
+        _lib.check(self.lib.ihm2mpc_get_status(self._h, out.ctypes.data_as(_lib.c_int32_p)))
+        return out
+
+    def get_qp_iter(self):
+        out = np.empty(self.B, dtype=np.int32)
+        _lib.check(self.lib.ihm2mpc_get_qp_iter(self._h, out.ctypes.data_as(_lib.c_int32_p)))
+        return out
+
+    def get_timings(self):
+        ms = np.zeros(3)
+        _lib.check(self.lib.ihm2mpc_get_timings(self._h, _ptr(ms), 3))
+        return {"total_ms": ms[0], "linearize_ms": ms[1], "qp_ms": ms[2]}
+
+    # ---- device-pointer variants (zero copy; dptr = integer device address, instance-major layout) ----
+    def set_x0_device(self, dptr: int):
+        _lib.check(self.lib.ihm2mpc_set_x0_device(self._h, C.c_void_p(dptr)))
+
+    def get_u0_device(self, dptr: int):
+        _lib.check(self.lib.ihm2mpc_get_u0_device(self._h, C.c_void_p(dptr)))
+
+    def get_x_device(self, dptr: int):
+        _lib.check(self.lib.ihm2mpc_get_x_device(self._h, C.c_void_p(dptr)))
+
+    def get_u_device(self, dptr: int):
+        _lib.check(self.lib.ihm2mpc_get_u_device(self._h, C.c_void_p(dptr)))
+
+    def get_status_device(self, dptr: int):
+        _lib.check(self.lib.ihm2mpc_get_status_device(self._h, C.c_void_p(dptr)))
+
+    # ---- plant ----
+    def sim_step(self, x, u, model: int = 0, M_sim: int = 100):
+        x = _f64(x, (self.B, NX), "x"); u = _f64(u, (self.B, NU), "u")
+        out = np.empty((self.B, NX))
+        _lib.check(self.lib.ihm2mpc_sim_step(self._h, int(model), int(M_sim), _ptr(x), _ptr(u), _ptr(out)))
+        return out
+
+    def sim_advance(self, model: int = 0, M_sim: int = 100):
+        """x0 <- plant(x0, u0 of the last solve), on device."""
+        _lib.check(self.lib.ihm2mpc_sim_advance(self._h, int(model), int(M_sim)))
+
+    # ---- single stage of a single instance ----
+    def _set_stage(self, i, stage, field, value):
+        v = _f64(np.ravel(value))
+        _lib.check(self.lib.ihm2mpc_set_stage(self._h, i, stage, field.encode(), _ptr(v), v.size))
+
+    def _get_stage(self, i, stage, field, n):
+        out = np.empty(n)
+        _lib.check(self.lib.ihm2mpc_get_stage(self._h, i, stage, field.encode(), _ptr(out), n))
+        return out
+
+
+class AcadosOcpSolver:
+    """Per-instance shim with the method names and semantics of ``acados_template.AcadosOcpSolver`` as
+    the reference uses them.  Built from an OCP it owns a batch of one; ``batch[i]`` gives a view."""
+
+    def __init__(self, ocp: AcadosOcp, json_file: str | None = None, verbose: bool = False, *, s_ref=None, kappa_ref=None,
+                 device: int = 0):
+        n_half = ocp.dims.np // 2
+        if s_ref is None:           # placeholder table until set(i, "p", p) arrives (python/main.py:249-252)
+            s_ref = np.arange(n_half, dtype=np.float64)
+            kappa_ref = np.zeros(n_half)
+        self.batch = BatchedOcpSolver(ocp, 1, s_ref, kappa_ref, device=device)
+        self.i = 0
+        self._owner = True
+
+    @classmethod
+    def _view(cls, batch: BatchedOcpSolver, i: int) -> "AcadosOcpSolver":
+        self = cls.__new__(cls)
+        self.batch, self.i, self._owner = batch, i, False
+        return self
+
+    @property
+    def N(self):
+        return self.batch.N
+
+    # -- set -------------------------------------------------------------------------------------
+    def set(self, stage: int, field: str, value) -> None:
+        b = self.batch
+        if field == "p":
+            p = _f64(np.ravel(value))
+            if p.size != 2 * b.nknots:
+                raise ValueError(f"p must have {2 * b.nknots} entries [s_ref; kappa_ref], got {p.size}")
+            t = int(b._track_id[self.i])       # the table is per track, not per stage: same p for all stages
+            if not (np.array_equal(b._s_ref[t], p[:b.nknots]) and np.array_equal(b._kappa_ref[t], p[b.nknots:])):
+                b._s_ref[t], b._kappa_ref[t] = p[:b.nknots], p[b.nknots:]
+                b._push_tracks()
+        elif field in ("lbx", "ubx"):
+            self.constraints_set(stage, field, value)
+        elif field in ("x", "u", "pi", "lam"):
+            b._set_stage(self.i, stage, field, value)
+        elif field in ("yref", "y_ref"):
+            v = np.ravel(value)
+            if stage == b.N:
+                # the C++ node hands a 12-vector at the terminal stage too (quirk Q8): keep the first 8
+                b._set_stage(self.i, 0, "yref_e", v[:NX])
+            else:
+                b._set_stage(self.i, stage, "yref", v)
+        else:
+            raise Exception(f"AcadosOcpSolver.set(): '{field}' is not a valid argument.")
+
+    def cost_set(self, stage: int, field: str, value, api: str = "warn") -> None:
+        if field != "W":
+            raise Exception(f"AcadosOcpSolver.cost_set(): '{field}' is not a valid argument.")
+        b = self.batch
+        W = np.asarray(value, dtype=np.float64)
+        if stage == b.N:
+            if W.shape != (NX, NX):
+                raise Exception(f"terminal W must be {NX}x{NX}")
+            b.data.W_e = W.copy()
+        else:
+            if W.shape != (NY, NY):
+                raise Exception(f"stage W must be {NY}x{NY}")
+            b.data.W[stage] = W
+        b._push_weights()
+
+    def constraints_set(self, stage: int, field: str, value, api: str = "warn") -> None:
+        b, d, c = self.batch, self.batch.data, self.batch.ocp.constraints
+        v = np.asarray(value, dtype=np.float64)
+        if field in ("lbx", "ubx") and stage == 0:
+            b._set_stage(self.i, 0, field, v)      # initial-state equality (python/main.py:299-300)
+            return
+        if field in ("lbx", "ubx"):
+            idx = np.asarray(c.idxbx_e if stage == b.N else c.idxbx, dtype=int)
+            getattr(d, field)[stage, idx] = v
+        elif field in ("lbu", "ubu"):
+            getattr(d, field)[stage, np.asarray(c.idxbu, dtype=int)] = v
+        elif field in ("C", "D"):
+            getattr(d, field)[stage, :v.shape[0]] = v
+        elif field in ("lg", "ug"):
+            getattr(d, field)[stage, :v.size] = v
+        else:
+            raise Exception(f"AcadosOcpSolver.constraints_set(): '{field}' is not a valid argument.")
+        b._push_bounds()
+
+    # -- solve / get -----------------------------------------------------------------------------
+    def solve(self) -> int:
+        """Runs the solver (for a view: the whole batch) and returns this instance's status."""
+        return int(self.batch.solve()[self.i])
+
+    def get(self, stage: int, field: str) -> np.ndarray:
+        sizes = {"x": NX, "u": NU, "pi": NX, "lam": NLAM}
+        if field not in sizes:
+            raise Exception(f"AcadosOcpSolver.get(): '{field}' is not a valid argument.")
+        return self.batch._get_stage(self.i, stage, field, sizes[field])
+
+    def get_stats(self, field: str):
+        if field == "residuals":
+            return self.batch.get_residuals()[self.i]
+        if field in ("qp_iter", "sqp_iter"):
+            return int(self.batch.get_qp_iter()[self.i]) if field == "qp_iter" else 1
+        if field == "time_tot":
+            return self.batch.get_timings()["total_ms"] * 1e-3
+        raise Exception(f"AcadosOcpSolver.get_stats(): '{field}' is not a valid argument.")
+
+    def get_status(self) -> int:
+        return int(self.batch.get_status()[self.i])
+
+
+def get_acados_solver(ocp: AcadosOcp, opts: AcadosOcpOptions, gen_code_dir: str | None = None, **kw) -> AcadosOcpSolver:
+    """``python/mpc.py:104-113``; nothing is generated or compiled, ``gen_code_dir`` is accepted and ignored."""
+    ocp.solver_options = opts
+    return AcadosOcpSolver(ocp, json_file=None, verbose=False, **kw)

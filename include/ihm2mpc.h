@@ -1,0 +1,152 @@
+/*
+ * ihm2mpc.h -- C ABI of libihm2mpc.so: batched SQP-RTI solver for the ihm2 path-parametric
+ * bicycle NMPC on AMD MI355X (gfx950).  Plain C: opaque handle, pointers and sizes only.
+ *
+ * This is the drop-in boundary for the reference's NMPC hot path.  Each entry point replaces an
+ * acados call the reference makes (file:line relative to tudoroancea/ihm2):
+ *
+ *   ihm2mpc_create            <- AcadosOcpSolver(ocp, json_file=...)            python/mpc.py:111-113
+ *                                ihm2_fkin6_acados_create_capsule/_create       src/ihm2/src/mpc_control_node.cpp:274-284
+ *   ihm2mpc_free              <- ihm2_fkin6_acados_free/_free_capsule           mpc_control_node.cpp:398-412
+ *   ihm2mpc_set_tracks        <- solver.set(i, "p", p) for all stages           python/main.py:249-252
+ *                                ihm2_fkin6_acados_update_params                mpc_control_node.cpp:360-364
+ *   ihm2mpc_set_weights       <- solver.cost_set(i, "W", W)                     python/main.py:253-295; mpc_control_node.cpp:287-293
+ *   ihm2mpc_set_bounds        <- ocp.constraints.* / constraints_set(i,"lbx"..) python/mpc.py:79-99; dpc/main.py:226-227,259-261
+ *   ihm2mpc_set_x0            <- solver.set(0,"lbx",x); set(0,"ubx",x)          python/main.py:299-300; mpc_control_node.cpp:177-179
+ *   ihm2mpc_set_yref(_e)      <- solver.set(j,"yref",..)                        python/main.py:303-314; mpc_control_node.cpp:183-186
+ *   ihm2mpc_set_x / _set_u    <- solver.set(j,"x"/"u",..) (warm start)          python/main.py:317-322
+ *   ihm2mpc_prepare_step      <- the whole of python/main.py:303-322 on device (reference ramp + shift)
+ *   ihm2mpc_solve             <- solver.solve()                                 python/main.py:325; mpc_control_node.cpp:189
+ *   ihm2mpc_get_x/_u/_u0      <- solver.get(i,"x"/"u")                          python/main.py:331-334; mpc_control_node.cpp:202-206
+ *   ihm2mpc_get_status        <- return value of solve()                        python/main.py:325-328; dpc/main.py:287-293
+ *   ihm2mpc_get_residuals     <- solver.get_stats("residuals") (acados)
+ *   ihm2mpc_sim_step          <- AcadosSimSolver.simulate(x,u)                  python/main.py:476-502; python/sim.py:9-25
+ *
+ * Conventions
+ *   x = (s, n, psi, v_x, v_y, r, T, delta), u = (u_T, u_delta)   (python/models.py:236-245)
+ *   All host arrays are C-contiguous, instance-major: x (B,N+1,8), u (B,N,2), yref (B,N,12) ...
+ *   Every setter copies in, every getter copies out; no caller pointer is kept after return.
+ *   A handle owns its device memory and one HIP stream; it is not thread-safe; distinct handles
+ *   are independent (one per device for multi-GPU sharding).
+ *   Return value: 0 = ok, < 0 = API misuse or HIP error (text in ihm2mpc_last_error()).
+ *   Per-instance solver status (acados codes): 0 success, 1 NaN/failure, 2 max iterations (SQP
+ *   mode), 3 min step, 4 QP failure.  The reference accepts {0, 2} (python/main.py:326).
+ */
+#ifndef IHM2MPC_H
+#define IHM2MPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IHM2MPC_NX 8
+#define IHM2MPC_NU 2
+#define IHM2MPC_NY 12
+#define IHM2MPC_NYE 8
+#define IHM2MPC_NG 2
+#define IHM2MPC_NLAM 24 /* multipliers per stage: lower (8 bx, 2 bu, 2 g) then upper (8, 2, 2) */
+#define IHM2MPC_NMAX 128
+
+#define IHM2MPC_MODEL_FKIN6 0 /* python/models.py:232-307 */
+#define IHM2MPC_MODEL_FDYN6 1 /* python/models.py:455-606 */
+
+#define IHM2MPC_SQP_RTI 0 /* old/generate.py:21 */
+#define IHM2MPC_SQP 1     /* python/main.py:230 */
+
+typedef struct ihm2mpc_handle ihm2mpc_handle;
+
+typedef struct ihm2mpc_config {
+    int32_t batch;          /* B: independent MPC instances on this device */
+    int32_t N;              /* shooting intervals (python/main.py:183: Nf = 40) */
+    int32_t M;              /* RK4 sub-steps per interval (sim_method_num_steps); >= 20 for stability */
+    int32_t model;          /* IHM2MPC_MODEL_* of the OCP */
+    int32_t ntracks;        /* number of track tables */
+    int32_t nknots;         /* knots per table (python/motion_planning.py:25,402-428: 3*500) */
+    int32_t device;         /* HIP device ordinal */
+    int32_t nlp_solver_type;     /* IHM2MPC_SQP_RTI or IHM2MPC_SQP */
+    int32_t nlp_solver_max_iter; /* SQP mode: iterations per solve() (python/main.py:231) */
+    int32_t ipm_iter_max;   /* interior-point iteration cap */
+    double dt;              /* interval length (python/main.py:184) */
+    double cost_scale_stage;/* factor on the stage cost terms (acados: the time step) */
+    double ipm_tol;         /* relative tolerance of the QP solver */
+    double ipm_mu0;         /* initial barrier parameter factor */
+    double ipm_tau0;        /* initial slack floor */
+    double nlp_tol;         /* SQP mode: KKT tolerance */
+} ihm2mpc_config;
+
+const char *ihm2mpc_last_error(void);
+const char *ihm2mpc_version(void);
+
+int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out);
+int ihm2mpc_free(ihm2mpc_handle *h);
+int ihm2mpc_synchronize(ihm2mpc_handle *h);
+/* the handle's hipStream_t, as void* (for callers that enqueue their own work behind a solve) */
+int ihm2mpc_get_stream(ihm2mpc_handle *h, void **stream);
+
+/* ---- problem data shared by the whole batch ---- */
+int ihm2mpc_set_tracks(ihm2mpc_handle *h, const double *s_ref, const double *kappa_ref); /* (ntracks,nknots) each */
+int ihm2mpc_set_track_id(ihm2mpc_handle *h, const int32_t *track_id);                     /* (B) */
+int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e);           /* (N,12,12), (8,8) */
+/* lbx/ubx (N+1,8) [row 0 unused], lbu/ubu (N,2), C (N,2,8), D (N,2,2), lg/ug (N,2); +-inf = absent */
+int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, const double *lbu,
+                       const double *ubu, const double *C, const double *D, const double *lg,
+                       const double *ug);
+
+/* ---- per-instance data ---- */
+int ihm2mpc_set_x0(ihm2mpc_handle *h, const double *x0);         /* (B,8) */
+int ihm2mpc_set_x(ihm2mpc_handle *h, const double *x);           /* (B,N+1,8) */
+int ihm2mpc_set_u(ihm2mpc_handle *h, const double *u);           /* (B,N,2) */
+int ihm2mpc_set_yref(ihm2mpc_handle *h, const double *yref);     /* (B,N,12) */
+int ihm2mpc_set_yref_e(ihm2mpc_handle *h, const double *yref_e); /* (B,8) */
+int ihm2mpc_set_multipliers(ihm2mpc_handle *h, const double *pi, const double *lam); /* (B,N+1,8), (B,N+1,24); NULL = zero */
+
+/* one stage of one instance (the AcadosOcpSolver.set/get call shape); field is one of
+ * "x","u","yref","yref_e","lbx","ubx" (stage 0 only: both set x0),"pi","lam" */
+int ihm2mpc_set_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const char *field,
+                      const double *value, int32_t n);
+int ihm2mpc_get_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const char *field,
+                      double *value, int32_t n);
+
+/* ---- the hot path ---- */
+/* initial guess: roll the model out from x0 under a Stanley-type feedback (python/main.py:99-163) */
+int ihm2mpc_init_guess(ihm2mpc_handle *h, double v_ref_scale);
+/* reference ramp yref_j = [s0 + s_target*j/N, 0..], yref_e = [s0 + s_target, 0..] from the current
+ * x0, and warm-start shift of (x,u) -- python/main.py:303-322 -- entirely on device */
+int ihm2mpc_prepare_step(ihm2mpc_handle *h, double s_target);
+/* n_iter RTI iterations (n_iter <= 0: the configured nlp_solver_max_iter / 1 for SQP_RTI) */
+int ihm2mpc_solve(ihm2mpc_handle *h, int32_t n_iter);
+/* phases of solve(), exposed for parity tests and profiling */
+int ihm2mpc_linearize(ihm2mpc_handle *h);
+int ihm2mpc_get_linearization(ihm2mpc_handle *h, double *A, double *Bm, double *b); /* (B,N,8,8),(B,N,8,2),(B,N,8) */
+
+int ihm2mpc_get_x(ihm2mpc_handle *h, double *x);
+int ihm2mpc_get_u(ihm2mpc_handle *h, double *u);
+int ihm2mpc_get_u0(ihm2mpc_handle *h, double *u0);              /* (B,2) */
+int ihm2mpc_get_status(ihm2mpc_handle *h, int32_t *status);     /* (B) */
+int ihm2mpc_get_qp_iter(ihm2mpc_handle *h, int32_t *qp_iter);   /* (B) */
+int ihm2mpc_get_residuals(ihm2mpc_handle *h, double *res);      /* (B,4): stat, eq, ineq, comp */
+int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam);
+/* milliseconds of the last solve(): [0] total, [1] linearize, [2] qp+update (HIP events) */
+int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n);
+
+/* ---- device-pointer variants (zero-copy closed loop, RCCL gather of results) ----
+ * dptr is device memory on the handle's device, SAME (instance-major) layout as the host variant */
+int ihm2mpc_set_x0_device(ihm2mpc_handle *h, const void *dptr);
+int ihm2mpc_get_u0_device(ihm2mpc_handle *h, void *dptr);
+int ihm2mpc_get_x_device(ihm2mpc_handle *h, void *dptr);
+int ihm2mpc_get_u_device(ihm2mpc_handle *h, void *dptr);
+int ihm2mpc_get_status_device(ihm2mpc_handle *h, void *dptr);
+
+/* ---- plant step (closed-loop MiL): x_next = RK4 x M_sim over dt of `model` under u ---- */
+int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const double *x,
+                     const double *u, double *x_next); /* host (B,8),(B,2) -> (B,8) */
+/* on device: x0 <- plant(x0, u0 of the last solve); model = -1: kin/dyn switch of python/main.py:482-489 */
+int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim);
+int ihm2mpc_get_x0(ihm2mpc_handle *h, double *x0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

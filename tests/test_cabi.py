@@ -1,0 +1,56 @@
+"""The C-ABI shared library loads and exports every symbol include/ihm2mpc.h declares (no compute:
+runs without a GPU), and the product never routes through the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ihm2mpc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ihm2mpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = _declared_symbols()
+    for must in ("ihm2mpc_create", "ihm2mpc_free", "ihm2mpc_solve", "ihm2mpc_set_x0", "ihm2mpc_get_u0",
+                 "ihm2mpc_get_status", "ihm2mpc_set_tracks", "ihm2mpc_set_weights", "ihm2mpc_prepare_step"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from ihm2_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/ihm2mpc.h but not exported"
+    assert set(_lib.SYMBOLS) == set(_declared_symbols())      # the ctypes table covers the header, no extras
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import shutil
+
+    from ihm2_amd import _lib
+
+    lib = _lib.load()
+    if shutil.which("rocminfo") and os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    cfg = _lib.Config(batch=1, N=10, M=25, model=0, ntracks=1, nknots=10, device=0, nlp_solver_type=0,
+                      nlp_solver_max_iter=1, ipm_iter_max=10, dt=0.05, cost_scale_stage=0.05, ipm_tol=1e-6,
+                      ipm_mu0=0.03, ipm_tau0=0.1, nlp_tol=1e-6)
+    h = ctypes.c_void_p()
+    assert lib.ihm2mpc_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"hip" in lib.ihm2mpc_last_error().lower()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "ihm2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
