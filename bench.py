@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- NMPC RTI solves/s of the batched bicycle NMPC on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], per GPU): batch = 1024 kinematic bicycle (fkin6) instances, N = 40,
+dt = 0.05, RK4 x M = 25, track fsds_competition_1, synthetic Monte-Carlo initial states of SURVEY.md 8d.
+One "step" = one closed-loop control step of the whole batch, everything resident on the device:
+plant advance (kinematic model, RK4 x 25) -> reference ramp + warm-start shift (python/main.py:303-322)
+-> one SQP-RTI iteration (linearise, QP, full step) -> read back u0 (B x 2) to the host.
+Weak scaling: every rank owns its own 1024 instances on its own GPU; no data-path collective; RCCL is
+used for the barrier / max-reduce of the timing and for one final all_gather of the results.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (live HIP-event time on the
+solver's stream); `cpu_baseline` is the CPU oracle (own restatement, NOT acados) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_H, DT, M_SUB, S_TARGET = 40, 0.05, 25, 40.0
+TRACK = "fsds_competition_1"
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector peak = fp64 matrix peak (guide: MI355X_MICROARCH.md / SURVEY.md 8d)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_problem(batch):
+    from ihm2_amd import ocp as O
+    from ihm2_amd.track import track_table
+
+    track = track_table(TRACK)
+    model = O.get_acados_model_from_explicit_dynamics("ihm2_fkin6", O.fkin6_model, 8, 2, 3000)
+    ocp = O.get_acados_ocp(model, N_H, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)      # python/main.py:186-192 defaults
+    ocp.cost.W, ocp.cost.W_e = O.default_weights()                            # python/main.py:193-210
+    ocp.solver_options.tf = N_H * DT
+    ocp.solver_options.sim_method_num_steps = M_SUB
+    return ocp, track
+
+
+def sample_x0(track, B, seed):
+    """SURVEY.md section 8d."""
+    from ihm2_amd.constants import l_R
+
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(0, track.lap_length, B)
+    n = rng.uniform(-0.5, 0.5, B)
+    psi = rng.uniform(-0.1, 0.1, B)
+    vx = rng.uniform(2, 15, B)
+    kap = np.interp(s, track.s_ref, track.kappa_ref)
+    T = rng.uniform(-100, 300, B)
+    delta = np.arctan(2 * np.tan(np.arcsin(np.clip(kap * l_R, -0.9, 0.9))))
+    return np.stack([s, n, psi, vx, 0 * s, vx * kap, T, delta], 1)
+
+
+def flops_per_solve(n_ipm):
+    """Algorithmic flop model of SURVEY.md 8d (fkin6): linearisation + structure-exploiting QP."""
+    nx, nu = 8, 2
+    lin = N_H * M_SUB * 4 * (2 * nx * nx * (nx + nu) + 400)
+    qp = n_ipm * N_H * 1800.0
+    return lin, qp
+
+
+def cpu_baseline(ocp, track, x0_all, budget_s=12.0):
+    """Oracle (own C restatement, OpenMP over instances) on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+
+    P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+    threads = orc.num_threads()
+    Bs = min(256, x0_all.shape[0])
+    x0 = x0_all[:Bs].copy()
+    x = np.zeros((Bs, N_H + 1, 8)); u = np.zeros((Bs, N_H, 2)); x[:, 0] = x0
+    for k in range(N_H):      # held-input rollout as a cheap initial guess
+        u[:, k] = x0[:, 6:8]
+        x[:, k + 1] = P.sim_step(x[:, k], u[:, k], 0, M_SUB)
+    x[:, :, 1] = np.clip(x[:, :, 1], -1.5, 1.5)
+    pi = lam = None
+    xcur = x0
+    solves, t_acc, steps = 0, 0.0, 0
+    while t_acc < budget_s and steps < 200:
+        xcur = P.sim_step(xcur, u[:, 0].copy(), 0, M_SUB)
+        t0 = time.perf_counter()
+        yref, yref_e = orc.prepare_step(N_H, xcur, S_TARGET, x, u)
+        out = P.rti_step(x, u, xcur, yref, yref_e, pi=pi, lam=lam)
+        t_acc += time.perf_counter() - t0
+        pi, lam = out["pi"], out["lam"]
+        solves += Bs
+        steps += 1
+    return {"value": solves / t_acc, "unit": "solves/s", "cores": threads, "kind": "port",
+            "sample": f"{Bs} instances x {steps} RTI steps of the same workload ({t_acc:.1f} s of CPU work), "
+                      f"oracle/libihm2_oracle.so with OpenMP over instances; own CPU restatement, not acados"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU (BASELINE configs[1]: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = args.batch
+    ocp, track = build_problem(B)
+    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, device=local_rank)
+    x0 = sample_x0(track, B, seed=20240607 + rank)
+    solver.set_x0(x0)
+    solver.init_guess()
+
+    def step():
+        solver.sim_advance(model=0, M_sim=M_SUB)
+        solver.prepare_step(S_TARGET)
+        solver.solve_async()
+        return solver.get_u0()        # device -> host, synchronises the solver's stream
+
+    def barrier():
+        solver.synchronize()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_lin = t_qp = 0.0
+    step_ms = []
+    qp_iters = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+        tm = solver.get_timings()      # HIP events recorded on the solver's stream around the kernels
+        t_lin += tm["linearize_ms"]; t_qp += tm["qp_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    qp_iters = solver.get_qp_iter()
+    status = solver.get_status()
+
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # final gather of the results over RCCL/xGMI: u0 (B,2) and status of every rank, device to device
+        tg0 = time.perf_counter()
+        u0_dev = torch.empty((B, 2), dtype=torch.float64, device="cuda")
+        st_dev = torch.empty((B,), dtype=torch.int32, device="cuda")
+        solver.get_u0_device(u0_dev.data_ptr()); solver.get_status_device(st_dev.data_ptr()); solver.synchronize()
+        u0_all = [torch.empty_like(u0_dev) for _ in range(world)]
+        st_all = [torch.empty_like(st_dev) for _ in range(world)]
+        dist.all_gather(u0_all, u0_dev); dist.all_gather(st_all, st_dev)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg0) * 1e3
+        status_all = torch.cat(st_all).cpu().numpy()
+    else:
+        gather_ms = 0.0
+        status_all = status
+
+    if rank == 0:
+        total_solves = B * world * args.steps
+        value = total_solves / elapsed
+        n_ipm = float(np.mean(qp_iters))
+        f_lin, f_qp = flops_per_solve(n_ipm)
+        ms_lin, ms_qp = t_lin / args.steps, t_qp / args.steps
+        if ms_lin >= ms_qp:
+            kname, kms, kflops = "k_linearize_fkin6", ms_lin, f_lin * B
+        else:
+            kname, kms, kflops = "k_qp_lane", ms_qp, f_qp * B
+        achieved = kflops / (kms * 1e-3) / 1e12
+        alg_bytes = 8 * (2 * (N_H + 1) * 8 + 2 * N_H * 2 + 8 + 5)          # 6632 B per solve
+        out = {
+            "metric": "NMPC RTI solves/s (batch), N=40, nx=8 (6-DOF bicycle), fkin6",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={B}/GPU kinematic bicycle fkin6, N=40, dt=0.05, RK4 x M={M_SUB}, "
+                                   f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 readback",
+                       "batch_per_gpu": B, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards"},
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "note": "fp64 VALU/latency-bound path (no MFMA on it): peak = MI355X fp64 vector = fp64 matrix "
+                                 "peak; achieved = algorithmic flops (SURVEY.md 8d model) / HIP-event kernel time",
+                         "kernel_ms": kms, "linearize_ms": ms_lin, "qp_ms": ms_qp, "n_ipm_mean": n_ipm, "M": M_SUB,
+                         "alg_flops_per_solve": f_lin + f_qp,
+                         "hbm_fraction_algorithmic": alg_bytes * value / world / 1e9 / HBM_PEAK_GBS},
+            "latency_ms_p50_batch": float(np.percentile(step_ms, 50)), "latency_ms_p99_batch": float(np.percentile(step_ms, 99)),
+            "status_counts": {str(k): int(v) for k, v in enumerate(np.bincount(status_all, minlength=5)) if v},
+            "gather_ms": gather_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ocp, track, x0, args.cpu_budget)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    solver.free()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,28 +47,18 @@ int dalloc(T **p, size_t n)
     return 0;
 }
 
-// host AoS (B, elems) -> device SoA
-int upload(ihm2mpc_handle *h, const double *host, double *soa, int elems)
+// host (B, elems) <-> device (B, elems): same instance-major layout on both sides
+int upload(ihm2mpc_handle *h, const double *host, double *dev, int elems)
 {
-    const size_t n = (size_t)h->B * elems;
-    if (n > h->stage_elems) return fail("staging buffer too small");
-    memcpy(h->stage_h, host, n * sizeof(double));
-    HIP_TRY(hipMemcpyAsync(h->stage_d, h->stage_h, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    ihm2_launch_aos_to_soa(h, h->stage_d, soa, elems);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));   // stage_h is reused by the next setter
+    HIP_TRY(hipMemcpyAsync(dev, host, (size_t)h->B * elems * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the caller's buffer may be reused as soon as we return
     return 0;
 }
 
-int download(ihm2mpc_handle *h, const double *soa, double *host, int elems)
+int download(ihm2mpc_handle *h, const double *dev, double *host, int elems)
 {
-    const size_t n = (size_t)h->B * elems;
-    if (n > h->stage_elems) return fail("staging buffer too small");
-    ihm2_launch_soa_to_aos(h, soa, h->stage_d, elems);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->stage_h, h->stage_d, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(host, dev, (size_t)h->B * elems * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    memcpy(host, h->stage_h, n * sizeof(double));
     return 0;
 }
 
@@ -142,29 +132,21 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     memset(h, 0, sizeof *h);
     h->cfg = *cfg;
     h->B = cfg->batch;
-    h->Bp = (cfg->batch + 63) / 64 * 64;
     h->N = cfg->N;
     h->NS = cfg->N + 1;
-    const size_t Bp = h->Bp, N = h->N, NS = h->NS;
+    const size_t B = h->B, N = h->N, NS = h->NS;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[i]));
 #define DA(p, n) if (dalloc(&h->p, (n))) return -1
     DA(s_ref, (size_t)cfg->ntracks * cfg->nknots); DA(kappa_ref, (size_t)cfg->ntracks * cfg->nknots);
-    DA(track_id, Bp);
+    DA(track_id, B);
     DA(Hs, NS * 100); DA(Gy, NS * 120); DA(lbx, NS * 8); DA(ubx, NS * 8); DA(lbu, N * 2); DA(ubu, N * 2);
     DA(CD, N * 20); DA(lg, N * 2); DA(ug, N * 2);
-    DA(x, NS * 8 * Bp); DA(u, N * 2 * Bp); DA(x0, 8 * Bp); DA(yref, N * 12 * Bp); DA(yref_e, 8 * Bp);
-    DA(pi, NS * 8 * Bp); DA(lam, NS * 24 * Bp); DA(res, 4 * Bp); DA(status, Bp); DA(qp_iter, Bp); DA(u0, 2 * Bp);
-    DA(A, N * 64 * Bp); DA(Bm, N * 16 * Bp); DA(bvec, N * 8 * Bp);
-    DA(q_g, NS * 10 * Bp); DA(q_dl, NS * 12 * Bp); DA(q_du, NS * 12 * Bp); DA(q_z, NS * 10 * Bp); DA(q_pi, NS * 8 * Bp);
-    DA(q_lam, NS * 24 * Bp); DA(q_t, NS * 24 * Bp); DA(q_gt, NS * 10 * Bp); DA(q_rb, N * 8 * Bp); DA(q_rd, NS * 24 * Bp);
-    DA(q_dz, NS * 10 * Bp); DA(q_dpi, NS * 8 * Bp); DA(q_dlam, NS * 24 * Bp); DA(q_dt, NS * 24 * Bp);
-    DA(q_dlam_a, NS * 24 * Bp); DA(q_dt_a, NS * 24 * Bp); DA(q_P, NS * 36 * Bp); DA(q_Gux, N * 16 * Bp);
-    DA(q_Ginv, N * 3 * Bp); DA(q_p, NS * 8 * Bp); DA(q_kff, N * 2 * Bp);
+    DA(slot_kc, NS * 12); DA(slot_lb, NS * 12); DA(slot_ub, NS * 12);
+    DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
+    DA(pi, B * NS * 8); DA(lam, B * NS * 24); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(u0, B * 2);
+    DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(scratch, B * 24);
 #undef DA
-    h->stage_elems = (size_t)h->B * (N * 64 > NS * 24 ? N * 64 : NS * 24);
-    HIP_TRY(hipMalloc((void **)&h->stage_d, h->stage_elems * sizeof(double)));
-    HIP_TRY(hipHostMalloc((void **)&h->stage_h, h->stage_elems * sizeof(double), hipHostMallocDefault));
     *out = h;
     return 0;
 }
@@ -175,12 +157,9 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->status, h->qp_iter, h->u0, h->A, h->Bm,
-                    h->bvec, h->q_g, h->q_dl, h->q_du, h->q_z, h->q_pi, h->q_lam, h->q_t, h->q_gt, h->q_rb, h->q_rd, h->q_dz,
-                    h->q_dpi, h->q_dlam, h->q_dt, h->q_dlam_a, h->q_dt_a, h->q_P, h->q_Gux, h->q_Ginv, h->q_p, h->q_kff,
-                    h->stage_d};
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
+                    h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (h->stage_h) (void)hipHostFree(h->stage_h);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -285,6 +264,28 @@ int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, 
             for (int j = 0; j < NX; j++) CD[((size_t)k * 2 + r) * 10 + j] = C[((size_t)k * 2 + r) * NX + j];
             for (int j = 0; j < NU; j++) CD[((size_t)k * 2 + r) * 10 + 8 + j] = D[((size_t)k * 2 + r) * NU + j];
         }
+    // compact table of the constraint slots (stage, row) that have at least one finite side
+    std::vector<int32_t> kc; std::vector<double> slb, sub;
+    int m_act = 0;
+    for (int k = 0; k < NS; k++)
+        for (int c = 0; c < NC; c++) {
+            double lb = -INFINITY, ub = INFINITY;
+            if (c < 8) { if (k >= 1) { lb = lbx[k * 8 + c]; ub = ubx[k * 8 + c]; } }
+            else if (c < 10) { if (k < N) { lb = lbu[k * 2 + c - 8]; ub = ubu[k * 2 + c - 8]; } }
+            else { if (k < N) { lb = lg[k * 2 + c - 10]; ub = ug[k * 2 + c - 10]; } }
+            const bool fl = std::fabs(lb) < 1e20, fu = std::fabs(ub) < 1e20;
+            if (!fl && !fu) continue;
+            kc.push_back(k * 12 + c); slb.push_back(fl ? lb : -INFINITY); sub.push_back(fu ? ub : INFINITY);
+            m_act += (int)fl + (int)fu;
+        }
+    if (kc.size() > 8 * 64) return fail("%zu constraint slots exceed the kernel limit of 512 (8 per lane)", kc.size());
+    h->nslots = (int)kc.size();
+    h->m_act = m_act;
+    if (!kc.empty()) {
+        HIP_TRY(hipMemcpyAsync(h->slot_kc, kc.data(), kc.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (upload_shared(h, slb.data(), h->slot_lb, slb.size()) || upload_shared(h, sub.data(), h->slot_ub, sub.size())) return -1;
+    }
     if (upload_shared(h, lbx, h->lbx, (size_t)NS * 8) || upload_shared(h, ubx, h->ubx, (size_t)NS * 8) ||
         upload_shared(h, lbu, h->lbu, (size_t)N * 2) || upload_shared(h, ubu, h->ubu, (size_t)N * 2) ||
         upload_shared(h, CD.data(), h->CD, CD.size()) || upload_shared(h, lg, h->lg, (size_t)N * 2) ||
@@ -312,10 +313,9 @@ int ihm2mpc_set_multipliers(ihm2mpc_handle *h, const double *pi, const double *l
 {
     CHECK_H(h);
     if (pi) { if (upload(h, pi, h->pi, h->NS * NX)) return -1; }
-    else { ihm2_launch_fill(h, h->pi, h->NS * NX, 0.0); }
+    else HIP_TRY(hipMemsetAsync(h->pi, 0, (size_t)h->B * h->NS * NX * sizeof(double), h->stream));
     if (lam) { if (upload(h, lam, h->lam, h->NS * NLAM)) return -1; }
-    else { ihm2_launch_fill(h, h->lam, h->NS * NLAM, 0.0); }
-    HIP_TRY(hipGetLastError());
+    else HIP_TRY(hipMemsetAsync(h->lam, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
     return 0;
 }
 
@@ -332,8 +332,8 @@ int ihm2mpc_set_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const 
     if (f == "yref_e") stage = 0;
     if (stage < 0 || stage >= fi.nstages) return fail("stage %d out of range for field '%s'", stage, field);
     if (n != fi.per_stage) return fail("field '%s' has %d entries per stage, got %d", field, fi.per_stage, n);
-    double *dst = fi.base + (size_t)stage * fi.per_stage * h->Bp + instance;
-    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)h->Bp * sizeof(double), value, sizeof(double), sizeof(double), n, hipMemcpyHostToDevice, h->stream));
+    double *dst = fi.base + ((size_t)instance * fi.nstages + stage) * fi.per_stage;
+    HIP_TRY(hipMemcpyAsync(dst, value, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -348,8 +348,8 @@ int ihm2mpc_get_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const 
     if (std::string(field) == "yref_e") stage = 0;
     if (stage < 0 || stage >= fi.nstages) return fail("stage %d out of range for field '%s'", stage, field);
     if (n != fi.per_stage) return fail("field '%s' has %d entries per stage, got %d", field, fi.per_stage, n);
-    const double *src = fi.base + (size_t)stage * fi.per_stage * h->Bp + instance;
-    HIP_TRY(hipMemcpy2DAsync(value, sizeof(double), src, (size_t)h->Bp * sizeof(double), sizeof(double), n, hipMemcpyDeviceToHost, h->stream));
+    const double *src = fi.base + ((size_t)instance * fi.nstages + stage) * fi.per_stage;
+    HIP_TRY(hipMemcpyAsync(value, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -389,7 +389,7 @@ int ihm2mpc_solve(ihm2mpc_handle *h, int32_t n_iter)
     for (int it = 0; it < n_iter; it++) {
         ihm2_launch_linearize(h);
         if (it == n_iter - 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-        ihm2_launch_qp(h);
+        if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
     }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(hipGetLastError());
@@ -411,9 +411,15 @@ int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n)
 int ihm2mpc_get_linearization(ihm2mpc_handle *h, double *A, double *Bm, double *b)
 {
     CHECK_H(h);
-    if (A && download(h, h->A, A, h->N * 64)) return -1;
-    if (Bm && download(h, h->Bm, Bm, h->N * 16)) return -1;
-    if (b && download(h, h->bvec, b, h->N * 8)) return -1;
+    const size_t n = (size_t)h->B * h->N;
+    std::vector<double> rec(n * LIN_REC);
+    HIP_TRY(hipMemcpyAsync(rec.data(), h->lin, rec.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (size_t r = 0; r < n; r++) {
+        if (A) memcpy(A + r * 64, rec.data() + r * LIN_REC, 64 * sizeof(double));
+        if (Bm) memcpy(Bm + r * 16, rec.data() + r * LIN_REC + 64, 16 * sizeof(double));
+        if (b) memcpy(b + r * 8, rec.data() + r * LIN_REC + 80, 8 * sizeof(double));
+    }
     return 0;
 }
 
@@ -458,45 +464,24 @@ int ihm2mpc_get_qp_iter(ihm2mpc_handle *h, int32_t *qp_iter)
 }
 
 // ---- device-pointer variants: instance-major device buffers, no host round trip ----
-int ihm2mpc_set_x0_device(ihm2mpc_handle *h, const void *dptr)
-{
-    CHECK_H(h);
-    if (!dptr) return fail("null argument");
-    ihm2_launch_aos_to_soa(h, (const double *)dptr, h->x0, NX);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-int ihm2mpc_get_u0_device(ihm2mpc_handle *h, void *dptr)
-{
-    CHECK_H(h);
-    if (!dptr) return fail("null argument");
-    ihm2_launch_soa_to_aos(h, h->u0, (double *)dptr, NU);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-int ihm2mpc_get_x_device(ihm2mpc_handle *h, void *dptr)
-{
-    CHECK_H(h);
-    if (!dptr) return fail("null argument");
-    ihm2_launch_soa_to_aos(h, h->x, (double *)dptr, h->NS * NX);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-int ihm2mpc_get_u_device(ihm2mpc_handle *h, void *dptr)
-{
-    CHECK_H(h);
-    if (!dptr) return fail("null argument");
-    ihm2_launch_soa_to_aos(h, h->u, (double *)dptr, h->N * NU);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-int ihm2mpc_get_status_device(ihm2mpc_handle *h, void *dptr)
-{
-    CHECK_H(h);
-    if (!dptr) return fail("null argument");
-    HIP_TRY(hipMemcpyAsync(dptr, h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-    return 0;
-}
+#define DEVCOPY(name, dst, src, bytes)                                                                  \
+    int ihm2mpc_##name(ihm2mpc_handle *h, DEVCOPY_ARG dptr)                                             \
+    {                                                                                                   \
+        CHECK_H(h);                                                                                     \
+        if (!dptr) return fail("null argument");                                                        \
+        HIP_TRY(hipMemcpyAsync((void *)(dst), (const void *)(src), (bytes), hipMemcpyDeviceToDevice, h->stream)); \
+        return 0;                                                                                       \
+    }
+#define DEVCOPY_ARG const void *
+DEVCOPY(set_x0_device, h->x0, dptr, (size_t)h->B * NX * sizeof(double))
+#undef DEVCOPY_ARG
+#define DEVCOPY_ARG void *
+DEVCOPY(get_u0_device, dptr, h->u0, (size_t)h->B * NU * sizeof(double))
+DEVCOPY(get_x_device, dptr, h->x, (size_t)h->B * h->NS * NX * sizeof(double))
+DEVCOPY(get_u_device, dptr, h->u, (size_t)h->B * h->N * NU * sizeof(double))
+DEVCOPY(get_status_device, dptr, h->status, (size_t)h->B * sizeof(int32_t))
+#undef DEVCOPY_ARG
+#undef DEVCOPY
 
 // ---- plant ----
 int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const double *x, const double *u, double *x_next)
@@ -506,8 +491,7 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
     if (!x || !u || !x_next) return fail("null argument");
     if (M_sim < 1) return fail("M_sim must be >= 1");
     if (model < -1 || model > IHM2MPC_MODEL_FDYN6) return fail("unknown plant model %d", model);
-    // scratch: the QP step buffers are free between solves
-    double *xs = h->q_dz, *us = h->q_dpi, *xn = h->q_gt;
+    double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
     if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
     ihm2_launch_sim(h, model, M_sim, xs, us, xn);
     HIP_TRY(hipGetLastError());

@@ -6,8 +6,8 @@
 // (python/main.py:325; options old/generate.py:23-25 with sim_method_num_steps = M).
 // RK4 tableau as dpc/main.py:87-97.
 //
-// Mapping: one lane per (b, k) pair, b fastest, so a wavefront covers 64 consecutive instances of one
-// interval and every global access is one coalesced 512-byte row of the SoA arrays.
+// Mapping: one lane per (b, k) pair, k fastest (instance-major arrays): a wavefront reads 64
+// consecutive 64-byte state rows (4 KB contiguous) and writes 64 consecutive 704-byte records.
 // Sensitivities are held column-wise in registers; only the 52 structurally non-zero entries of the
 // 8x10 matrix are stored and only the 31 non-zeros of the model Jacobian are multiplied
 // (model.hpp: JX_MASK / S_COL_MASK).  Algorithmic traffic per pair: read 10 + 8 doubles, write 88.
@@ -55,20 +55,21 @@ __device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&d
 #define FOR_ALL_COLS(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9)
 
 __global__ __launch_bounds__(64) void k_linearize_fkin6(
-    int B, int Bp, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
+    int B, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
     const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *__restrict__ xs,
-    const double *__restrict__ us, double *__restrict__ Aout, double *__restrict__ Bout, double *__restrict__ bout)
+    const double *__restrict__ us, double *__restrict__ lin)
 {
     const long t = (long)blockIdx.x * 64 + threadIdx.x;
-    const int b = (int)(t % Bp);
-    const int k = (int)(t / Bp);
-    if (k >= N || b >= B) return;
+    const int b = (int)(t / N);
+    const int k = (int)(t % N);
+    if (b >= B) return;
 
+    const double *xk = xs + ((size_t)b * (N + 1) + k) * 8;
     double x[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)(k * 8 + i) * Bp + b];
-    const double u_T = us[(size_t)(k * 2 + 0) * Bp + b];
-    const double u_d = us[(size_t)(k * 2 + 1) * Bp + b];
+    for (int i = 0; i < 8; i++) x[i] = xk[i];
+    const double u_T = us[((size_t)b * N + k) * 2 + 0];
+    const double u_d = us[((size_t)b * N + k) * 2 + 1];
     const int tid = track_id[b];
     TrackSeg trk;
     trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
@@ -106,26 +107,21 @@ __global__ __launch_bounds__(64) void k_linearize_fkin6(
         FOR_ALL_COLS(COPY_ACC_TO_S)
     }
 
-    // outputs: A (8x8 row-major), Bm (8x2), b = Phi(x_k,u_k) - x_{k+1}
+    // output record [A (8x8 row-major) | B (8x2) | b = Phi(x_k,u_k) - x_{k+1}]
+    double *rec = lin + ((size_t)b * N + k) * LIN_REC;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const double v = ((S_COL_MASK[j] >> i) & 1u) ? S[j][i] : 0.0;
-            Aout[(size_t)((k * 8 + i) * 8 + j) * Bp + b] = v;
-        }
+        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[j] >> i) & 1u) ? S[j][i] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const double v = ((S_COL_MASK[8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
-            Bout[(size_t)((k * 8 + i) * 2 + j) * Bp + b] = v;
-        }
-        bout[(size_t)(k * 8 + i) * Bp + b] = x[i] - xs[(size_t)((k + 1) * 8 + i) * Bp + b];
+        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
+        rec[80 + i] = x[i] - xk[8 + i];
     }
 }
 
 // plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 = kin/dyn switch of
 // python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic)
-__global__ __launch_bounds__(64) void k_sim_step(int B, int Bp, int model, int M, double dt, int nknots,
+__global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double dt, int nknots,
                                                  const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                                  const int32_t *__restrict__ track_id, const double *xs,
                                                  const double *__restrict__ us, double *xn)
@@ -134,8 +130,8 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int Bp, int model, int M
     if (b >= B) return;
     double x[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)i * Bp + b];
-    const double u_T = us[b], u_d = us[(size_t)Bp + b];
+    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)b * 8 + i];
+    const double u_T = us[(size_t)b * 2], u_d = us[(size_t)b * 2 + 1];
     const int tid = track_id[b];
     TrackSeg trk;
     trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
@@ -167,22 +163,22 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int Bp, int model, int M
         for (int i = 0; i < 8; i++) x[i] = xacc[i];
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) xn[(size_t)i * Bp + b] = x[i];
+    for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = x[i];
 }
 
 }  // namespace
 
 void ihm2_launch_linearize(ihm2mpc_handle *h)
 {
-    const long total = (long)h->Bp * h->N;
+    const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
-    hipLaunchKernelGGL(k_linearize_fkin6, dim3(blocks), dim3(64), 0, h->stream, h->B, h->Bp, h->N, h->cfg.M, h->cfg.dt,
-                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->A, h->Bm, h->bvec);
+    hipLaunchKernelGGL(k_linearize_fkin6, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
 }
 
-void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x_soa, const double *u_soa, double *xn_soa)
+void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn)
 {
     const int blocks = (h->B + 63) / 64;
-    hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, h->stream, h->B, h->Bp, model, M_sim, h->cfg.dt,
-                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x_soa, u_soa, xn_soa);
+    hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, h->stream, h->B, model, M_sim, h->cfg.dt,
+                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn);
 }

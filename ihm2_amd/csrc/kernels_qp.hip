@@ -10,492 +10,577 @@
 // an equality-constrained LQ problem solved by a Riccati recursion (backward factor+vector sweep,
 // forward sweep).  Tolerances are relative to sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
 //
-// v1 mapping: ONE LANE PER INSTANCE.  Every per-instance array is SoA [elem][Bp] in global memory so
-// that a wavefront touches 64 consecutive doubles per access.  Per-stage 8x8/10x10 blocks live in
-// registers with compile-time indices.  (DESIGN.md discusses the wave-per-instance successor.)
+// Mapping: ONE WAVEFRONT PER INSTANCE (block = 64 lanes).
+//   * iterate z, pi, the modified gradient, Riccati vectors and gains: LDS (about 39 KB at N = 40);
+//   * multipliers / slacks / their steps: registers, each lane owns NSLOT two-sided constraint slots
+//     (320 slots at the reference's dimensions = 5 per lane);
+//   * per-stage records [A|B|b] (704 B) and P_k (512 B): one coalesced wave access each from HBM/L2,
+//     prefetched one stage ahead of the sequential sweeps;
+//   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands read from LDS (broadcast rows,
+//     consecutive columns: conflict-free), wave reductions by cross-lane shuffles.
 #include "ihm2mpc_internal.h"
 
 namespace {
 
 struct QpArgs {
-    int B, Bp, N, iter_max;
+    int B, N, iter_max, nslots, m_act;
     double tol, mu0, tau0;
     // shared
-    const double *Hs, *Gy, *lbx, *ubx, *lbu, *ubu, *CD, *lg, *ug;
+    const double *Hs, *Gy, *CD, *slot_lb, *slot_ub;
+    const int32_t *slot_kc;
     // per instance
     double *x, *u;
     const double *x0, *yref, *yref_e;
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
-    const double *A, *Bm, *bvec;
-    double *g, *dl, *du, *z, *qpi, *qlam, *qt, *gt, *rb, *rd, *dz, *dpi, *dlam, *dt, *dlam_a, *dt_a, *P, *Gux, *Ginv, *p, *kff;
+    const double *lin;
+    double *g, *P;
 };
 
 #define INF_BOUND 1e20
-#define AT(arr, e) a.arr[(size_t)(e) * Bp + b]
 
 __device__ __forceinline__ bool fin(double v) { return fabs(v) < INF_BOUND; }
-__device__ __forceinline__ constexpr int sym8(int i, int j) { return (i <= j) ? (i * 8 - i * (i - 1) / 2 + (j - i)) : (j * 8 - j * (j - 1) / 2 + (i - j)); }
-__device__ __forceinline__ constexpr int sym10(int i, int j) { return (i <= j) ? (i * 10 - i * (i - 1) / 2 + (j - i)) : (j * 10 - j * (j - 1) / 2 + (i - j)); }
 
-// R_c . v for the 12 constraint rows of stage k: rows 0..9 are unit vectors, rows 10, 11 are [C D]_k
-__device__ __forceinline__ void rows_times(const QpArgs &a, int k, int N, const double (&v)[10], double (&out)[12])
+__device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
-    for (int c = 0; c < 10; c++) out[c] = v[c];
-    out[10] = 0.0; out[11] = 0.0;
-    if (k < N) {
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
 #pragma unroll
-        for (int j = 0; j < 10; j++) {
-            out[10] = fma(a.CD[(k * 2 + 0) * 10 + j], v[j], out[10]);
-            out[11] = fma(a.CD[(k * 2 + 1) * 10 + j], v[j], out[11]);
-        }
-    }
+    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// NaN-propagating max (fmax drops NaNs): used where a NaN must surface in the residual
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+__device__ __forceinline__ double wave_nanmax(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = nanmax(v, __shfl_xor(v, o));
+    return v;
 }
 
-__global__ __launch_bounds__(64) void k_qp_lane(QpArgs a)
+// upper-triangle enumeration of a 10x10 symmetric matrix: entry e in [0,55) -> (i <= j)
+__device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    const int B = a.B, Bp = a.Bp, N = a.N, NS = N + 1;
-    if (b >= B) return;
+    int r = 0, rem = e;
+#pragma unroll
+    for (int q = 0; q < 9; q++)
+        if (r == q && rem >= 10 - q) { rem -= 10 - q; r = q + 1; }
+    i = r; j = r + rem;
+}
+
+template <int NSLOT>
+__global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
+{
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int N = a.N, NS = N + 1;
+    if (b >= a.B) return;
+
+    // ---- LDS carve-up (doubles) ----
+    double *z = sm;                  // NS*10  QP iterate
+    double *gt = z + NS * 10;        // NS*10  stationarity residual / modified gradient
+    double *pi = gt + NS * 10;       // NS*8   QP costates
+    double *pv = pi + NS * 8;        // NS*8   Riccati vector p_k, overwritten by dpi_k in the last forward sweep
+    double *rb = pv + NS * 8;        // N*8    dynamics residual
+    double *Rz = rb + N * 8;         // NS*12  R z (then R dz)
+    double *bufA = Rz + NS * 12;     // NS*12  lam_l - lam_u / gradient coefficients / dz (NS*10)
+    double *gam = bufA + NS * 12;    // NS*12  barrier weights
+    double *kff = gam + NS * 12;     // N*2
+    double *Gux = kff + N * 2;       // N*16
+    double *Ginv = Gux + N * 16;     // N*4 (3 used)
+    double *Prb = Ginv + N * 4;      // N*8   P_{k+1} rb_k (same for predictor and corrector)
+    double *Pn = Prb + N * 8;        // 64
+    double *ABs = Pn + 64;           // 80   [l][10]
+    double *Ws = ABs + 80;           // 80   [l][10]
+    double *Gs = Ws + 80;            // 100
+    double *hs = Gs + 100;           // 8
+    double *gz = hs + 8;             // 10 (+2 pad)
+    double *dxs = gz + 12;           // 8
+    double *dus = dxs + 8;           // 2 (+2 pad)
+    double *dz = bufA;
+
+    const double *xb = a.x + (size_t)b * NS * 8;
+    const double *ub = a.u + (size_t)b * N * 2;
+    const double *linb = a.lin + (size_t)b * N * LIN_REC;
+    double *gb = a.g + (size_t)b * NS * 10;
+    double *Pb = a.P + (size_t)b * NS * 64;
+    double *pib = a.pi + (size_t)b * NS * 8;
+    double *lamb = a.lam + (size_t)b * NS * 24;
 
     // ------------------------------------------------------------------ QP data + NLP residuals
-    double sg = 1.0, sb = 1.0;
-    double r_stat = 0.0, r_eq = 0.0, r_ineq = 0.0, r_comp = 0.0;
-    int m_act = 0;
-    for (int k = 0; k <= N; k++) {
-        double zk[10];
+    // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
+    double sg = 1.0, sb = 1.0, r_stat = 0.0, r_eq = 0.0;
+    for (int e = lane; e < NS * 10; e += 64) {
+        const int k = e / 10, j = e % 10;
+        double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) zk[i] = AT(x, k * 8 + i);
-        zk[8] = (k < N) ? AT(u, k * 2 + 0) : 0.0;
-        zk[9] = (k < N) ? AT(u, k * 2 + 1) : 0.0;
-        double yr[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) yr[i] = (k < N) ? AT(yref, k * 12 + i) : ((i < 8) ? AT(yref_e, i) : 0.0);
-        double gk[10];
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < 10; j++) acc = fma(a.Hs[(k * 10 + i) * 10 + j], zk[j], acc);
-#pragma unroll
-            for (int j = 0; j < 12; j++) acc = fma(-a.Gy[(k * 10 + i) * 12 + j], yr[j], acc);
-            gk[i] = acc;
-            AT(g, k * 10 + i) = acc;
-            if (i < 8 || k < N) sg = fmax(sg, fabs(acc));
-        }
-        // bounds relative to the current iterate
-        double cz[12], dlk[12], duk[12];
-        rows_times(a, k, N, zk, cz);
-#pragma unroll
-        for (int c = 0; c < 12; c++) {
-            double lb = -INFINITY, ub = INFINITY;
-            if (c < 8) { if (k >= 1) { lb = a.lbx[k * 8 + c]; ub = a.ubx[k * 8 + c]; } }
-            else if (c < 10) { if (k < N) { lb = a.lbu[k * 2 + c - 8]; ub = a.ubu[k * 2 + c - 8]; } }
-            else { if (k < N) { lb = a.lg[k * 2 + c - 10]; ub = a.ug[k * 2 + c - 10]; } }
-            dlk[c] = fin(lb) ? lb - cz[c] : -INFINITY;
-            duk[c] = fin(ub) ? ub - cz[c] : INFINITY;
-            AT(dl, k * 12 + c) = dlk[c];
-            AT(du, k * 12 + c) = duk[c];
-            const double ll = AT(lam, k * 24 + c), lu = AT(lam, k * 24 + 12 + c);
-            if (fin(dlk[c])) { m_act++; r_ineq = fmax(r_ineq, dlk[c]); r_comp = fmax(r_comp, fabs(ll * dlk[c])); }
-            if (fin(duk[c])) { m_act++; r_ineq = fmax(r_ineq, -duk[c]); r_comp = fmax(r_comp, fabs(lu * duk[c])); }
-        }
-        // stationarity of the NLP Lagrangian with the incoming multipliers
-        double st[10];
-#pragma unroll
-        for (int j = 0; j < 10; j++) st[j] = gk[j];
+        for (int l = 0; l < 8; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], xb[k * 8 + l], acc);
         if (k < N) {
+            acc = fma(a.Hs[(k * 10 + j) * 10 + 8], ub[k * 2 + 0], acc);
+            acc = fma(a.Hs[(k * 10 + j) * 10 + 9], ub[k * 2 + 1], acc);
+            const double *yr = a.yref + ((size_t)b * N + k) * 12;
 #pragma unroll
-            for (int l = 0; l < 8; l++) {
-                const double pl = AT(pi, (k + 1) * 8 + l);
+            for (int l = 0; l < 12; l++) acc = fma(-a.Gy[(k * 10 + j) * 12 + l], yr[l], acc);
+        } else {
+            const double *yr = a.yref_e + (size_t)b * 8;
 #pragma unroll
-                for (int j = 0; j < 8; j++) st[j] = fma(AT(A, (k * 8 + l) * 8 + j), pl, st[j]);
-                st[8] = fma(AT(Bm, (k * 8 + l) * 2 + 0), pl, st[8]);
-                st[9] = fma(AT(Bm, (k * 8 + l) * 2 + 1), pl, st[9]);
-                const double bl = AT(bvec, k * 8 + l);
-                sb = fmax(sb, fabs(bl));
-                r_eq = fmax(r_eq, fabs(bl));
-            }
+            for (int l = 0; l < 8; l++) acc = fma(-a.Gy[(k * 10 + j) * 12 + l], yr[l], acc);
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) st[j] -= AT(pi, k * 8 + j);
-#pragma unroll
-        for (int c = 0; c < 10; c++) st[c] -= AT(lam, k * 24 + c) - AT(lam, k * 24 + 12 + c);
+        gb[e] = acc;
+        const bool counted = !((k == 0 && j < 8) || (k == N && j >= 8));
+        if (j < 8 || k < N) sg = fmax(sg, fabs(acc));
+        // stationarity: g + AB' pi_{k+1} - [pi_k;0] - R'(lam_l - lam_u)
+        double st = acc;
         if (k < N) {
+            const double *rec = linb + (size_t)k * LIN_REC;
 #pragma unroll
-            for (int c = 10; c < 12; c++) {
-                const double d = AT(lam, k * 24 + c) - AT(lam, k * 24 + 12 + c);
-#pragma unroll
-                for (int j = 0; j < 10; j++) st[j] = fma(-a.CD[(k * 2 + c - 10) * 10 + j], d, st[j]);
-            }
+            for (int l = 0; l < 8; l++) st = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pib[(k + 1) * 8 + l], st);
         }
+        if (j < 8) st -= pib[k * 8 + j];
+        st -= lamb[k * 24 + j] - lamb[k * 24 + 12 + j];
+        if (k < N) {
+            st = fma(-a.CD[(k * 2 + 0) * 10 + j], lamb[k * 24 + 10] - lamb[k * 24 + 22], st);
+            st = fma(-a.CD[(k * 2 + 1) * 10 + j], lamb[k * 24 + 11] - lamb[k * 24 + 23], st);
+        }
+        if (counted) r_stat = fmax(r_stat, fabs(st));
+    }
+    for (int e = lane; e < N * 8; e += 64) {
+        const double bl = linb[(size_t)(e / 8) * LIN_REC + 80 + (e % 8)];
+        sb = fmax(sb, fabs(bl));
+        r_eq = fmax(r_eq, fabs(bl));
+    }
+    if (lane < 8) {
+        const double d = a.x0[(size_t)b * 8 + lane] - xb[lane];
+        sb = fmax(sb, fabs(d));
+        r_eq = fmax(r_eq, fabs(d));
+    }
+    sg = wave_max(sg); sb = wave_max(sb);
+
+    // constraint slots owned by this lane
+    int s_kc[NSLOT];
+    double s_dl[NSLOT], s_du[NSLOT];      // bounds relative to the iterate (+-inf = absent)
+    double lam_l[NSLOT], lam_u[NSLOT], t_l[NSLOT], t_u[NSLOT];
+    double r_ineq = 0.0, r_comp = 0.0;
 #pragma unroll
-        for (int j = 0; j < 10; j++) {
-            if (k == 0 && j < 8) continue;
-            if (k == N && j >= 8) continue;
-            r_stat = fmax(r_stat, fabs(st[j]));
+    for (int r = 0; r < NSLOT; r++) {
+        const int s = lane + 64 * r;
+        s_kc[r] = -1; s_dl[r] = -INFINITY; s_du[r] = INFINITY;
+        lam_l[r] = lam_u[r] = 0.0; t_l[r] = t_u[r] = 1.0;
+        if (s < a.nslots) {
+            const int kc = a.slot_kc[s], k = kc / 12, c = kc % 12;
+            s_kc[r] = kc;
+            double cz;
+            if (c < 8) cz = xb[k * 8 + c];
+            else if (c < 10) cz = ub[k * 2 + c - 8];
+            else {
+                cz = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) cz = fma(a.CD[(k * 2 + c - 10) * 10 + j], xb[k * 8 + j], cz);
+                cz = fma(a.CD[(k * 2 + c - 10) * 10 + 8], ub[k * 2 + 0], cz);
+                cz = fma(a.CD[(k * 2 + c - 10) * 10 + 9], ub[k * 2 + 1], cz);
+            }
+            const double lb = a.slot_lb[s], ubd = a.slot_ub[s];
+            if (fin(lb)) { s_dl[r] = lb - cz; r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + c] * s_dl[r])); }
+            if (fin(ubd)) { s_du[r] = ubd - cz; r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + 12 + c] * s_du[r])); }
         }
     }
-    double dx0[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        dx0[i] = AT(x0, i) - AT(x, i);
-        sb = fmax(sb, fabs(dx0[i]));
-        r_eq = fmax(r_eq, fabs(dx0[i]));
+    r_stat = wave_max(r_stat); r_eq = wave_max(r_eq); r_ineq = wave_max(r_ineq); r_comp = wave_max(r_comp);
+    if (lane == 0) {
+        double *rs = a.res + (size_t)b * 4;
+        rs[0] = r_stat; rs[1] = r_eq; rs[2] = r_ineq; rs[3] = r_comp;
     }
-    AT(res, 0) = r_stat; AT(res, 1) = r_eq; AT(res, 2) = r_ineq; AT(res, 3) = r_comp;
 
     const double tol_g = a.tol * sg, tol_b = a.tol * sb, tol_d = a.tol * sb, tol_m = a.tol * sg;
     const double mu_floor = 0.1 * tol_m;
     const double mu0 = a.mu0 * sg;
+    const double inv_m = (a.m_act > 0) ? 1.0 / a.m_act : 0.0;
 
     // ------------------------------------------------------------------ initial point
-    for (int k = 0; k <= N; k++) {
-        double zk[10];
+    for (int e = lane; e < NS * 10; e += 64) z[e] = (e < 8) ? a.x0[(size_t)b * 8 + e] - xb[e] : 0.0;
+    for (int e = lane; e < NS * 8; e += 64) pi[e] = 0.0;
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 10; i++) { zk[i] = (k == 0 && i < 8) ? dx0[i] : 0.0; AT(z, k * 10 + i) = zk[i]; }
+    for (int r = 0; r < NSLOT; r++) {
+        if (s_kc[r] < 0) continue;
+        const int k = s_kc[r] / 12, c = s_kc[r] % 12;
+        double rz = 0.0;      // z = 0 except dx_0: only rows touching x at stage 0 see it
+        if (k == 0) {
+            if (c < 10) rz = z[c];
+            else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) AT(qpi, k * 8 + i) = 0.0;
-        double rz[12];
-        rows_times(a, k, N, zk, rz);
-#pragma unroll
-        for (int c = 0; c < 12; c++) {
-            const double l = AT(dl, k * 12 + c), uu = AT(du, k * 12 + c);
-            const bool al = fin(l), au = fin(uu);
-            double tau_c = a.tau0;
-            if (al && au) tau_c = fmin(a.tau0, 0.25 * (uu - l));
-            const double tl = al ? fmax(rz[c] - l, tau_c) : 1.0;
-            const double tu = au ? fmax(uu - rz[c], tau_c) : 1.0;
-            AT(qt, k * 24 + c) = tl; AT(qt, k * 24 + 12 + c) = tu;
-            AT(qlam, k * 24 + c) = al ? mu0 / tl : 0.0;
-            AT(qlam, k * 24 + 12 + c) = au ? mu0 / tu : 0.0;
+                for (int j = 0; j < 10; j++) rz = fma(a.CD[(c - 10) * 10 + j], z[j], rz);
+            }
         }
+        const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+        double tau_c = a.tau0;
+        if (al && au) tau_c = fmin(a.tau0, 0.25 * (s_du[r] - s_dl[r]));
+        if (al) { t_l[r] = fmax(rz - s_dl[r], tau_c); lam_l[r] = mu0 / t_l[r]; }
+        if (au) { t_u[r] = fmax(s_du[r] - rz, tau_c); lam_u[r] = mu0 / t_u[r]; }
     }
 
     // ------------------------------------------------------------------ interior-point iterations
     int qstatus = 1, it = 0;
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
-    const double inv_m = (m_act > 0) ? 1.0 / m_act : 0.0;
+    double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
+    double dla_l[NSLOT], dla_u[NSLOT], dta_l[NSLOT], dta_u[NSLOT];
     for (it = 0;; it++) {
-        // ---- residuals: rg -> gt, rb, rd ----
-        res_g = res_b = res_d = res_m = 0.0; mu = 0.0;
-        for (int k = 0; k <= N; k++) {
-            double zk[10], rz[12], rg[10];
+        // ---- R z ; lam_l - lam_u -> bufA ----
+        for (int e = lane; e < NS * 12; e += 64) {
+            const int k = e / 12, c = e % 12;
+            double v = 0.0;
+            if (c < 10) v = z[k * 10 + c];
+            else if (k < N) {
 #pragma unroll
-            for (int i = 0; i < 10; i++) zk[i] = AT(z, k * 10 + i);
-            rows_times(a, k, N, zk, rz);
-#pragma unroll
-            for (int j = 0; j < 10; j++) {
-                double acc = AT(g, k * 10 + j);
-#pragma unroll
-                for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], zk[l], acc);
-                rg[j] = acc;
+                for (int j = 0; j < 10; j++) v = fma(a.CD[(k * 2 + c - 10) * 10 + j], z[k * 10 + j], v);
             }
-            if (k < N) {
-                double rbk[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) rbk[i] = AT(bvec, k * 8 + i) - AT(z, (k + 1) * 10 + i);
-#pragma unroll
-                for (int l = 0; l < 8; l++) {
-                    const double pl = AT(qpi, (k + 1) * 8 + l);
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const double alj = AT(A, (k * 8 + l) * 8 + j);
-                        rg[j] = fma(alj, pl, rg[j]);
-                        rbk[l] = fma(alj, zk[j], rbk[l]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const double blj = AT(Bm, (k * 8 + l) * 2 + j);
-                        rg[8 + j] = fma(blj, pl, rg[8 + j]);
-                        rbk[l] = fma(blj, zk[8 + j], rbk[l]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 8; i++) { AT(rb, k * 8 + i) = rbk[i]; res_b = fmax(res_b, fabs(rbk[i])); }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) rg[j] -= AT(qpi, k * 8 + j);
-            double dlam_c[12];
-#pragma unroll
-            for (int c = 0; c < 12; c++) {
-                const double l = AT(dl, k * 12 + c), uu = AT(du, k * 12 + c);
-                const bool al = fin(l), au = fin(uu);
-                const double ll = AT(qlam, k * 24 + c), lu = AT(qlam, k * 24 + 12 + c);
-                const double tl = AT(qt, k * 24 + c), tu = AT(qt, k * 24 + 12 + c);
-                dlam_c[c] = ll - lu;
-                const double rdl = al ? (rz[c] - tl - l) : 0.0;
-                const double rdu = au ? (uu - rz[c] - tu) : 0.0;
-                AT(rd, k * 24 + c) = rdl; AT(rd, k * 24 + 12 + c) = rdu;
-                res_d = fmax(res_d, fmax(fabs(rdl), fabs(rdu)));
-                if (al) { mu += ll * tl; res_m = fmax(res_m, fabs(ll * tl)); }
-                if (au) { mu += lu * tu; res_m = fmax(res_m, fabs(lu * tu)); }
-            }
-#pragma unroll
-            for (int c = 0; c < 10; c++) rg[c] -= dlam_c[c];
-            if (k < N) {
-#pragma unroll
-                for (int j = 0; j < 10; j++) {
-                    rg[j] = fma(-a.CD[(k * 2 + 0) * 10 + j], dlam_c[10], rg[j]);
-                    rg[j] = fma(-a.CD[(k * 2 + 1) * 10 + j], dlam_c[11], rg[j]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 10; j++) {
-                if ((k == 0 && j < 8) || (k == N && j >= 8)) rg[j] = 0.0;
-                AT(gt, k * 10 + j) = rg[j];
-                res_g = fmax(res_g, fabs(rg[j]));
-            }
+            Rz[e] = v;
+            bufA[e] = 0.0;
         }
-        mu *= inv_m;
+        __syncthreads();
+        double mu_acc = 0.0;
+        res_d = 0.0; res_m = 0.0;
+#pragma unroll
+        for (int r = 0; r < NSLOT; r++) {
+            rd_l[r] = rd_u[r] = 0.0;
+            if (s_kc[r] < 0) continue;
+            const double rz = Rz[s_kc[r]];
+            const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+            if (al) { rd_l[r] = rz - t_l[r] - s_dl[r]; mu_acc += lam_l[r] * t_l[r]; res_m = nanmax(res_m, fabs(lam_l[r] * t_l[r])); }
+            if (au) { rd_u[r] = s_du[r] - rz - t_u[r]; mu_acc += lam_u[r] * t_u[r]; res_m = nanmax(res_m, fabs(lam_u[r] * t_u[r])); }
+            res_d = nanmax(res_d, nanmax(fabs(rd_l[r]), fabs(rd_u[r])));
+            bufA[s_kc[r]] = lam_l[r] - lam_u[r];
+        }
+        __syncthreads();
+        // ---- stationarity and dynamics residuals ----
+        res_g = 0.0; res_b = 0.0;
+        for (int e = lane; e < NS * 10; e += 64) {
+            const int k = e / 10, j = e % 10;
+            double acc = gb[e];
+#pragma unroll
+            for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
+            if (k < N) {
+                const double *rec = linb + (size_t)k * LIN_REC;
+#pragma unroll
+                for (int l = 0; l < 8; l++) acc = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pi[(k + 1) * 8 + l], acc);
+                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], bufA[k * 12 + 10], acc);
+                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], bufA[k * 12 + 11], acc);
+            }
+            if (j < 8) acc -= pi[k * 8 + j];
+            acc -= bufA[k * 12 + j];
+            if ((k == 0 && j < 8) || (k == N && j >= 8)) acc = 0.0;
+            gt[e] = acc;
+            res_g = nanmax(res_g, fabs(acc));
+        }
+        for (int e = lane; e < N * 8; e += 64) {
+            const int k = e / 8, i = e % 8;
+            const double *rec = linb + (size_t)k * LIN_REC;
+            double acc = rec[80 + i] - z[(k + 1) * 10 + i];
+#pragma unroll
+            for (int l = 0; l < 8; l++) acc = fma(rec[i * 8 + l], z[k * 10 + l], acc);
+            acc = fma(rec[64 + i * 2 + 0], z[k * 10 + 8], acc);
+            acc = fma(rec[64 + i * 2 + 1], z[k * 10 + 9], acc);
+            rb[e] = acc;
+            res_b = nanmax(res_b, fabs(acc));
+        }
+        res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m);
+        mu = wave_sum(mu_acc) * inv_m;
         if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; }
         if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; }
         if (it >= a.iter_max) { qstatus = 1; break; }
+        __syncthreads();
 
         double alpha = 1.0, sigma = 0.0;
         for (int pass = 0; pass < 2; pass++) {
-            // ---- backward Riccati sweep (pass 0: factor + vector; pass 1: vector only) ----
-            double Pn[36], pn[8];
-            for (int k = N; k >= 0; k--) {
-                // modified gradient and barrier weights of this stage
-                double gtk[10], gam[12];
+            // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
+            for (int e = lane; e < NS * 12; e += 64) { bufA[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
+            __syncthreads();
+            const double mu_t = fmax(sigma * mu, mu_floor);
 #pragma unroll
-                for (int j = 0; j < 10; j++) gtk[j] = AT(gt, k * 10 + j);
-                double coef[12];
-#pragma unroll
-                for (int c = 0; c < 12; c++) {
-                    const bool al = fin(AT(dl, k * 12 + c)), au = fin(AT(du, k * 12 + c));
-                    const double ll = AT(qlam, k * 24 + c), lu = AT(qlam, k * 24 + 12 + c);
-                    const double tl = AT(qt, k * 24 + c), tu = AT(qt, k * 24 + 12 + c);
-                    gam[c] = (al ? ll / tl : 0.0) + (au ? lu / tu : 0.0);
-                    double cf = 0.0;
-                    if (pass == 0) {
-                        if (al) cf += (ll * tl + ll * AT(rd, k * 24 + c)) / tl;
-                        if (au) cf -= (lu * tu + lu * AT(rd, k * 24 + 12 + c)) / tu;
-                    } else {
-                        const double mu_t = fmax(sigma * mu, mu_floor);
-                        if (al) cf += (AT(dlam_a, k * 24 + c) * AT(dt_a, k * 24 + c) - mu_t) / tl;
-                        if (au) cf -= (AT(dlam_a, k * 24 + 12 + c) * AT(dt_a, k * 24 + 12 + c) - mu_t) / tu;
-                    }
-                    coef[c] = cf;
-                }
-#pragma unroll
-                for (int c = 0; c < 10; c++) gtk[c] += coef[c];
-                if (k < N) {
-#pragma unroll
-                    for (int j = 0; j < 10; j++) {
-                        gtk[j] = fma(a.CD[(k * 2 + 0) * 10 + j], coef[10], gtk[j]);
-                        gtk[j] = fma(a.CD[(k * 2 + 1) * 10 + j], coef[11], gtk[j]);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 10; j++) AT(gt, k * 10 + j) = gtk[j];   // pass 1 adds its increment on top
-
-                if (k == N) {
-                    if (pass == 0) {
-#pragma unroll
-                        for (int i = 0; i < 8; i++)
-#pragma unroll
-                            for (int j = i; j < 8; j++) {
-                                double v = a.Hs[(k * 10 + i) * 10 + j];
-                                if (i == j) v += gam[i];
-                                Pn[sym8(i, j)] = v;
-                                AT(P, k * 36 + sym8(i, j)) = v;
-                            }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 36; e++) Pn[e] = AT(P, k * 36 + e);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; i++) { pn[i] = gtk[i]; AT(p, k * 8 + i) = gtk[i]; }
-                    continue;
-                }
-                // stage k < N
-                double AB[8][10];
-#pragma unroll
-                for (int l = 0; l < 8; l++) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) AB[l][j] = AT(A, (k * 8 + l) * 8 + j);
-                    AB[l][8] = AT(Bm, (k * 8 + l) * 2 + 0);
-                    AB[l][9] = AT(Bm, (k * 8 + l) * 2 + 1);
-                }
-                // h = P_{k+1} rb_k + p_{k+1} ;  gz = gt_k + AB' h
-                double hv[8], gz[10];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    double acc = pn[i];
-#pragma unroll
-                    for (int l = 0; l < 8; l++) acc = fma(Pn[sym8(i, l)], AT(rb, k * 8 + l), acc);
-                    hv[i] = acc;
-                }
-#pragma unroll
-                for (int j = 0; j < 10; j++) {
-                    double acc = gtk[j];
-#pragma unroll
-                    for (int l = 0; l < 8; l++) acc = fma(AB[l][j], hv[l], acc);
-                    gz[j] = acc;
-                }
-                double Gux[2][8], Gi[3];
+            for (int r = 0; r < NSLOT; r++) {
+                if (s_kc[r] < 0) continue;
+                const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+                double cf = 0.0;
                 if (pass == 0) {
-                    // G = Ht + AB' P AB, column by column (upper triangle)
-                    double G[55];
-#pragma unroll
-                    for (int j = 0; j < 10; j++) {
-                        double col[8];
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            double acc = 0.0;
-#pragma unroll
-                            for (int l = 0; l < 8; l++) acc = fma(Pn[sym8(i, l)], AB[l][j], acc);
-                            col[i] = acc;
-                        }
-#pragma unroll
-                        for (int i = 0; i <= j; i++) {
-                            double acc = a.Hs[(k * 10 + i) * 10 + j];
-                            if (i == j) acc += gam[j];
-                            acc = fma(gam[10] * a.CD[(k * 2 + 0) * 10 + i], a.CD[(k * 2 + 0) * 10 + j], acc);
-                            acc = fma(gam[11] * a.CD[(k * 2 + 1) * 10 + i], a.CD[(k * 2 + 1) * 10 + j], acc);
-#pragma unroll
-                            for (int l = 0; l < 8; l++) acc = fma(AB[l][i], col[l], acc);
-                            G[sym10(i, j)] = acc;
-                        }
-                    }
-                    const double g00 = G[sym10(8, 8)], g01 = G[sym10(8, 9)], g11 = G[sym10(9, 9)];
-                    const double idet = 1.0 / (g00 * g11 - g01 * g01);
-                    Gi[0] = g11 * idet; Gi[1] = -g01 * idet; Gi[2] = g00 * idet;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { Gux[0][j] = G[sym10(j, 8)]; Gux[1][j] = G[sym10(j, 9)]; }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { AT(Gux, k * 16 + j) = Gux[0][j]; AT(Gux, k * 16 + 8 + j) = Gux[1][j]; }
-                    AT(Ginv, k * 3 + 0) = Gi[0]; AT(Ginv, k * 3 + 1) = Gi[1]; AT(Ginv, k * 3 + 2) = Gi[2];
-                    // P_k = Gxx - Gux' Ginv Gux
-                    double Kg[2][8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        Kg[0][j] = Gi[0] * Gux[0][j] + Gi[1] * Gux[1][j];
-                        Kg[1][j] = Gi[1] * Gux[0][j] + Gi[2] * Gux[1][j];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; i++)
-#pragma unroll
-                        for (int j = i; j < 8; j++) {
-                            const double v = G[sym10(i, j)] - (Gux[0][i] * Kg[0][j] + Gux[1][i] * Kg[1][j]);
-                            Pn[sym8(i, j)] = v;
-                            AT(P, k * 36 + sym8(i, j)) = v;
-                        }
+                    if (al) cf += (lam_l[r] * t_l[r] + lam_l[r] * rd_l[r]) / t_l[r];
+                    if (au) cf -= (lam_u[r] * t_u[r] + lam_u[r] * rd_u[r]) / t_u[r];
+                    gam[s_kc[r]] = (al ? lam_l[r] / t_l[r] : 0.0) + (au ? lam_u[r] / t_u[r] : 0.0);
                 } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { Gux[0][j] = AT(Gux, k * 16 + j); Gux[1][j] = AT(Gux, k * 16 + 8 + j); }
-                    Gi[0] = AT(Ginv, k * 3 + 0); Gi[1] = AT(Ginv, k * 3 + 1); Gi[2] = AT(Ginv, k * 3 + 2);
-#pragma unroll
-                    for (int e = 0; e < 36; e++) Pn[e] = AT(P, k * 36 + e);
+                    if (al) cf += (dla_l[r] * dta_l[r] - mu_t) / t_l[r];
+                    if (au) cf -= (dla_u[r] * dta_u[r] - mu_t) / t_u[r];
                 }
-                const double kf0 = Gi[0] * gz[8] + Gi[1] * gz[9], kf1 = Gi[1] * gz[8] + Gi[2] * gz[9];
-                AT(kff, k * 2 + 0) = kf0; AT(kff, k * 2 + 1) = kf1;
+                bufA[s_kc[r]] = cf;
+            }
+            __syncthreads();
+            for (int e = lane; e < NS * 10; e += 64) {
+                const int k = e / 10, j = e % 10;
+                double acc = gt[e] + bufA[k * 12 + j];
+                if (k < N) {
+                    acc = fma(a.CD[(k * 2 + 0) * 10 + j], bufA[k * 12 + 10], acc);
+                    acc = fma(a.CD[(k * 2 + 1) * 10 + j], bufA[k * 12 + 11], acc);
+                }
+                gt[e] = acc;        // pass 1 adds its increment on top of the predictor's gradient
+            }
+            __syncthreads();
+
+            // ---- backward Riccati sweep ----
+            if (pass == 0) {
+                {   // terminal stage
+                    const int i = lane >> 3, j = lane & 7;
+                    double v = a.Hs[(N * 10 + i) * 10 + j];
+                    if (i == j) v += gam[N * 12 + i];
+                    Pn[lane] = v;
+                    Pb[(size_t)N * 64 + lane] = v;
+                    if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
+                }
+                // prefetch the record of stage N-1
+                double regA = linb[(size_t)(N - 1) * LIN_REC + lane];
+                double regB = (lane < 16) ? linb[(size_t)(N - 1) * LIN_REC + 64 + lane] : 0.0;
+                __syncthreads();
+                for (int k = N - 1; k >= 0; k--) {
+                    ABs[(lane >> 3) * 10 + (lane & 7)] = regA;
+                    if (lane < 16) ABs[(lane >> 1) * 10 + 8 + (lane & 1)] = regB;
+                    if (k > 0) {
+                        regA = linb[(size_t)(k - 1) * LIN_REC + lane];
+                        if (lane < 16) regB = linb[(size_t)(k - 1) * LIN_REC + 64 + lane];
+                    }
+                    __syncthreads();
+                    // W = P_{k+1} [A B]  (80 entries) ; h = P_{k+1} rb_k + p_{k+1}
+                    {
+                        const int i = lane / 10, j = lane % 10;      // entries 0..63
+                        double acc = 0.0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    pn[i] = gz[i] - (Gux[0][i] * kf0 + Gux[1][i] * kf1);
-                    AT(p, k * 8 + i) = pn[i];
+                        for (int l = 0; l < 8; l++) acc = fma(Pn[i * 8 + l], ABs[l * 10 + j], acc);
+                        Ws[lane] = acc;
+                        if (lane < 16) {
+                            const int e2 = 64 + lane, i2 = e2 / 10, j2 = e2 % 10;
+                            double acc2 = 0.0;
+#pragma unroll
+                            for (int l = 0; l < 8; l++) acc2 = fma(Pn[i2 * 8 + l], ABs[l * 10 + j2], acc2);
+                            Ws[e2] = acc2;
+                        } else if (lane < 24) {
+                            const int i2 = lane - 16;
+                            double acc2 = 0.0;
+#pragma unroll
+                            for (int l = 0; l < 8; l++) acc2 = fma(Pn[i2 * 8 + l], rb[k * 8 + l], acc2);
+                            Prb[k * 8 + i2] = acc2;
+                            hs[i2] = acc2 + pv[(k + 1) * 8 + i2];
+                        }
+                    }
+                    __syncthreads();
+                    // G = Ht + [A B]' W  (upper triangle, 55 entries) ; gz = gt_k + [A B]' h
+                    if (lane < 55) {
+                        int i, j;
+                        sym10_ij(lane, i, j);
+                        double acc = a.Hs[(k * 10 + i) * 10 + j];
+                        if (i == j) acc += gam[k * 12 + i];
+                        acc = fma(gam[k * 12 + 10] * a.CD[(k * 2 + 0) * 10 + i], a.CD[(k * 2 + 0) * 10 + j], acc);
+                        acc = fma(gam[k * 12 + 11] * a.CD[(k * 2 + 1) * 10 + i], a.CD[(k * 2 + 1) * 10 + j], acc);
+#pragma unroll
+                        for (int l = 0; l < 8; l++) acc = fma(ABs[l * 10 + i], Ws[l * 10 + j], acc);
+                        Gs[i * 10 + j] = acc;
+                        Gs[j * 10 + i] = acc;
+                    }
+                    if (lane < 10) {
+                        double acc = gt[k * 10 + lane];
+#pragma unroll
+                        for (int l = 0; l < 8; l++) acc = fma(ABs[l * 10 + lane], hs[l], acc);
+                        gz[lane] = acc;
+                    }
+                    __syncthreads();
+                    // P_k = Gxx - Gux' Guu^-1 Gux ; gains ; p_k
+                    {
+                        const double g00 = Gs[88], g01 = Gs[89], g11 = Gs[99];
+                        const double idet = 1.0 / (g00 * g11 - g01 * g01);
+                        const double Gi0 = g11 * idet, Gi1 = -g01 * idet, Gi2 = g00 * idet;
+                        const int i0 = lane >> 3, j0 = lane & 7;
+                        const int i = min(i0, j0), j = max(i0, j0);      // evaluate the symmetric pair identically
+                        const double ai = Gs[i * 10 + 8], bi = Gs[i * 10 + 9], cj = Gs[j * 10 + 8], dj = Gs[j * 10 + 9];
+                        const double v = Gs[i * 10 + j] - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
+                        Pn[lane] = v;
+                        Pb[(size_t)k * 64 + lane] = v;
+                        if (lane < 16) Gux[k * 16 + lane] = Gs[(lane & 7) * 10 + 8 + (lane >> 3)];
+                        if (lane == 0) { Ginv[k * 4 + 0] = Gi0; Ginv[k * 4 + 1] = Gi1; Ginv[k * 4 + 2] = Gi2; }
+                        const double kf0 = Gi0 * gz[8] + Gi1 * gz[9], kf1 = Gi1 * gz[8] + Gi2 * gz[9];
+                        if (lane < 2) kff[k * 2 + lane] = lane ? kf1 : kf0;
+                        if (lane < 8) pv[k * 8 + lane] = gz[lane] - (Gs[lane * 10 + 8] * kf0 + Gs[lane * 10 + 9] * kf1);
+                    }
+                    __syncthreads();
+                }
+            } else {
+                // vector-only sweep with the stored factorisation: lanes 0..9 hold column `lane` of [A B]_k
+                if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
+                double col[8];
+#pragma unroll
+                for (int l = 0; l < 8; l++)
+                    col[l] = (lane < 8) ? linb[(size_t)(N - 1) * LIN_REC + l * 8 + lane]
+                                        : ((lane < 10) ? linb[(size_t)(N - 1) * LIN_REC + 64 + l * 2 + (lane - 8)] : 0.0);
+                __syncthreads();
+                for (int k = N - 1; k >= 0; k--) {
+                    if (lane < 10) {
+                        double acc = gt[k * 10 + lane];
+#pragma unroll
+                        for (int l = 0; l < 8; l++) acc = fma(col[l], Prb[k * 8 + l] + pv[(k + 1) * 8 + l], acc);
+                        gz[lane] = acc;
+                    }
+                    if (k > 0) {
+#pragma unroll
+                        for (int l = 0; l < 8; l++)
+                            col[l] = (lane < 8) ? linb[(size_t)(k - 1) * LIN_REC + l * 8 + lane]
+                                                : ((lane < 10) ? linb[(size_t)(k - 1) * LIN_REC + 64 + l * 2 + (lane - 8)] : 0.0);
+                    }
+                    __syncthreads();
+                    {
+                        const double Gi0 = Ginv[k * 4 + 0], Gi1 = Ginv[k * 4 + 1], Gi2 = Ginv[k * 4 + 2];
+                        const double kf0 = Gi0 * gz[8] + Gi1 * gz[9], kf1 = Gi1 * gz[8] + Gi2 * gz[9];
+                        if (lane < 2) kff[k * 2 + lane] = lane ? kf1 : kf0;
+                        if (lane < 8) pv[k * 8 + lane] = gz[lane] - (Gux[k * 16 + lane] * kf0 + Gux[k * 16 + 8 + lane] * kf1);
+                    }
+                    __syncthreads();
                 }
             }
-            // ---- forward sweep + slack/multiplier steps + step length ----
-            double dx[8];
+
+            // ---- forward sweep: dz (into bufA), dpi (into pv, corrector pass or no inequalities) ----
+            const bool want_dpi = (pass == 1) || (a.m_act == 0);
+            if (lane < 8) dxs[lane] = 0.0;
+            // lanes 0..7: row `lane` of [A B]_k ; lanes 8..15: row lane-8 of P_k (when dpi is wanted)
+            double row[10];
 #pragma unroll
-            for (int i = 0; i < 8; i++) dx[i] = 0.0;
-            double amax = 1.0;
-            for (int k = 0; k <= N; k++) {
-                double dzk[10];
+            for (int l = 0; l < 10; l++) row[l] = 0.0;
+            if (lane < 8) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) dzk[i] = dx[i];
-                dzk[8] = 0.0; dzk[9] = 0.0;
-                if (k < N) {
+                for (int l = 0; l < 8; l++) row[l] = linb[lane * 8 + l];
+                row[8] = linb[64 + lane * 2]; row[9] = linb[64 + lane * 2 + 1];
+            } else if (lane < 16 && want_dpi) {
+#pragma unroll
+                for (int l = 0; l < 8; l++) row[l] = Pb[(lane - 8) * 8 + l];
+            }
+            __syncthreads();
+            for (int k = 0; k < N; k++) {
+                if (lane < 2) {
                     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) { t0 = fma(AT(Gux, k * 16 + j), dx[j], t0); t1 = fma(AT(Gux, k * 16 + 8 + j), dx[j], t1); }
-                    const double g0 = AT(Ginv, k * 3 + 0), g1 = AT(Ginv, k * 3 + 1), g2 = AT(Ginv, k * 3 + 2);
-                    dzk[8] = -(g0 * t0 + g1 * t1) - AT(kff, k * 2 + 0);
-                    dzk[9] = -(g1 * t0 + g2 * t1) - AT(kff, k * 2 + 1);
-                }
+                    for (int j = 0; j < 8; j++) { t0 = fma(Gux[k * 16 + j], dxs[j], t0); t1 = fma(Gux[k * 16 + 8 + j], dxs[j], t1); }
+                    const double Gi0 = Ginv[k * 4 + 0], Gi1 = Ginv[k * 4 + 1], Gi2 = Ginv[k * 4 + 2];
+                    const double du = lane ? (-(Gi1 * t0 + Gi2 * t1) - kff[k * 2 + 1]) : (-(Gi0 * t0 + Gi1 * t1) - kff[k * 2 + 0]);
+                    dus[lane] = du;
+                    dz[k * 10 + 8 + lane] = du;
+                } else if (lane >= 8 && lane < 16) {
+                    if (want_dpi) {
+                        double acc = pv[k * 8 + lane - 8];
 #pragma unroll
-                for (int j = 0; j < 10; j++) AT(dz, k * 10 + j) = dzk[j];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    double acc = AT(p, k * 8 + i);
-#pragma unroll
-                    for (int l = 0; l < 8; l++) acc = fma(AT(P, k * 36 + sym8(i, l)), dx[l], acc);
-                    AT(dpi, k * 8 + i) = acc;
-                }
-                // constraints of this stage
-                double drz[12];
-                rows_times(a, k, N, dzk, drz);
-#pragma unroll
-                for (int c = 0; c < 12; c++) {
-                    const bool al = fin(AT(dl, k * 12 + c)), au = fin(AT(du, k * 12 + c));
-                    const double mu_t = fmax(sigma * mu, mu_floor);
-                    if (al) {
-                        const double ll = AT(qlam, k * 24 + c), tl = AT(qt, k * 24 + c);
-                        const double rm = (pass == 0) ? ll * tl : ll * tl + AT(dlam_a, k * 24 + c) * AT(dt_a, k * 24 + c) - mu_t;
-                        const double dtl = drz[c] + AT(rd, k * 24 + c);
-                        const double dll = -(rm + ll * dtl) / tl;
-                        AT(dt, k * 24 + c) = dtl; AT(dlam, k * 24 + c) = dll;
-                        if (dtl < 0.0) amax = fmin(amax, -tl / dtl);
-                        if (dll < 0.0) amax = fmin(amax, -ll / dll);
-                    } else { AT(dt, k * 24 + c) = 0.0; AT(dlam, k * 24 + c) = 0.0; }
-                    if (au) {
-                        const double lu = AT(qlam, k * 24 + 12 + c), tu = AT(qt, k * 24 + 12 + c);
-                        const double rm = (pass == 0) ? lu * tu : lu * tu + AT(dlam_a, k * 24 + 12 + c) * AT(dt_a, k * 24 + 12 + c) - mu_t;
-                        const double dtu = -drz[c] + AT(rd, k * 24 + 12 + c);
-                        const double dlu = -(rm + lu * dtu) / tu;
-                        AT(dt, k * 24 + 12 + c) = dtu; AT(dlam, k * 24 + 12 + c) = dlu;
-                        if (dtu < 0.0) amax = fmin(amax, -tu / dtu);
-                        if (dlu < 0.0) amax = fmin(amax, -lu / dlu);
-                    } else { AT(dt, k * 24 + 12 + c) = 0.0; AT(dlam, k * 24 + 12 + c) = 0.0; }
-                }
-                if (k < N) {
-                    double dxn[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        double acc = AT(rb, k * 8 + i);
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(AT(A, (k * 8 + i) * 8 + l), dx[l], acc);
-                        acc = fma(AT(Bm, (k * 8 + i) * 2 + 0), dzk[8], acc);
-                        acc = fma(AT(Bm, (k * 8 + i) * 2 + 1), dzk[9], acc);
-                        dxn[i] = acc;
+                        for (int l = 0; l < 8; l++) acc = fma(row[l], dxs[l], acc);
+                        pv[k * 8 + lane - 8] = acc;        // dpi_k
                     }
+                } else if (lane >= 16 && lane < 24) {
+                    dz[k * 10 + lane - 16] = dxs[lane - 16];
+                }
+                __syncthreads();
+                double dxn = 0.0;
+                if (lane < 8) {
+                    dxn = rb[k * 8 + lane];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) dx[i] = dxn[i];
+                    for (int l = 0; l < 8; l++) dxn = fma(row[l], dxs[l], dxn);
+                    dxn = fma(row[8], dus[0], dxn);
+                    dxn = fma(row[9], dus[1], dxn);
+                }
+                // prefetch the rows of the next stage
+                if (lane < 8) {
+                    if (k + 1 < N) {
+                        const double *rec = linb + (size_t)(k + 1) * LIN_REC;
+#pragma unroll
+                        for (int l = 0; l < 8; l++) row[l] = rec[lane * 8 + l];
+                        row[8] = rec[64 + lane * 2]; row[9] = rec[64 + lane * 2 + 1];
+                    }
+                } else if (lane < 16 && want_dpi) {
+#pragma unroll
+                    for (int l = 0; l < 8; l++) row[l] = Pb[(size_t)(k + 1) * 64 + (lane - 8) * 8 + l];
+                }
+                __syncthreads();
+                if (lane < 8) dxs[lane] = dxn;
+                __syncthreads();
+            }
+            if (lane < 8) { dz[N * 10 + lane] = dxs[lane]; }
+            else if (lane < 10) { dz[N * 10 + lane] = 0.0; }
+            else if (lane >= 16 && lane < 24 && want_dpi) {
+                const int i = lane - 16;
+                double acc = pv[N * 8 + i];
+#pragma unroll
+                for (int l = 0; l < 8; l++) acc = fma(Pb[(size_t)N * 64 + i * 8 + l], dxs[l], acc);
+                pv[N * 8 + i] = acc;
+            }
+            __syncthreads();
+
+            // ---- R dz, slack / multiplier steps, step length ----
+            for (int e = lane; e < NS * 12; e += 64) {
+                const int k = e / 12, c = e % 12;
+                double v = 0.0;
+                if (c < 10) v = dz[k * 10 + c];
+                else if (k < N) {
+#pragma unroll
+                    for (int j = 0; j < 10; j++) v = fma(a.CD[(k * 2 + c - 10) * 10 + j], dz[k * 10 + j], v);
+                }
+                Rz[e] = v;
+            }
+            __syncthreads();
+            double amax = 1.0, mu_aff = 0.0;
+#pragma unroll
+            for (int r = 0; r < NSLOT; r++) {
+                dlam_l[r] = dlam_u[r] = dt_l[r] = dt_u[r] = 0.0;
+                if (s_kc[r] < 0) continue;
+                const double drz = Rz[s_kc[r]];
+                if (fin(s_dl[r])) {
+                    const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + dla_l[r] * dta_l[r] - mu_t;
+                    dt_l[r] = drz + rd_l[r];
+                    dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) / t_l[r];
+                    if (dt_l[r] < 0.0) amax = fmin(amax, -t_l[r] / dt_l[r]);
+                    if (dlam_l[r] < 0.0) amax = fmin(amax, -lam_l[r] / dlam_l[r]);
+                }
+                if (fin(s_du[r])) {
+                    const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + dla_u[r] * dta_u[r] - mu_t;
+                    dt_u[r] = -drz + rd_u[r];
+                    dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) / t_u[r];
+                    if (dt_u[r] < 0.0) amax = fmin(amax, -t_u[r] / dt_u[r]);
+                    if (dlam_u[r] < 0.0) amax = fmin(amax, -lam_u[r] / dlam_u[r]);
                 }
             }
+            amax = wave_min(amax);
             if (pass == 0) {
-                if (m_act == 0) { alpha = 1.0; break; }
-                double mu_aff = 0.0;
-                for (int e = 0; e < NS * 24; e++) {
-                    const int k = e / 24, c = e % 24;
-                    const bool act = (c < 12) ? fin(AT(dl, k * 12 + c)) : fin(AT(du, k * 12 + c - 12));
-                    const double dle = AT(dlam, e), dte = AT(dt, e);
-                    AT(dlam_a, e) = dle; AT(dt_a, e) = dte;
-                    if (act) mu_aff += (AT(qlam, e) + amax * dle) * (AT(qt, e) + amax * dte);
+                if (a.m_act == 0) { alpha = 1.0; break; }
+#pragma unroll
+                for (int r = 0; r < NSLOT; r++) {
+                    dla_l[r] = dlam_l[r]; dla_u[r] = dlam_u[r]; dta_l[r] = dt_l[r]; dta_u[r] = dt_u[r];
+                    if (s_kc[r] < 0) continue;
+                    if (fin(s_dl[r])) mu_aff += (lam_l[r] + amax * dlam_l[r]) * (t_l[r] + amax * dt_l[r]);
+                    if (fin(s_du[r])) mu_aff += (lam_u[r] + amax * dlam_u[r]) * (t_u[r] + amax * dt_u[r]);
                 }
-                mu_aff *= inv_m;
+                mu_aff = wave_sum(mu_aff) * inv_m;
                 const double ratio = (mu > 0.0) ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
             } else {
                 alpha = fmin(1.0, 0.995 * amax);
             }
+            __syncthreads();
         }
         if (alpha < 1e-12) { qstatus = 2; break; }
-        for (int k = 0; k <= N; k++) {
+        for (int e = lane; e < NS * 10; e += 64) z[e] = fma(alpha, dz[e], z[e]);
+        for (int e = lane; e < NS * 8; e += 64) pi[e] = fma(alpha, pv[e], pi[e]);
 #pragma unroll
-            for (int j = 0; j < 10; j++) AT(z, k * 10 + j) += alpha * AT(dz, k * 10 + j);
-#pragma unroll
-            for (int i = 0; i < 8; i++) AT(qpi, k * 8 + i) += alpha * AT(dpi, k * 8 + i);
-#pragma unroll
-            for (int c = 0; c < 24; c++) {
-                const bool act = (c < 12) ? fin(AT(dl, k * 12 + c)) : fin(AT(du, k * 12 + c - 12));
-                if (act) { AT(qlam, k * 24 + c) += alpha * AT(dlam, k * 24 + c); AT(qt, k * 24 + c) += alpha * AT(dt, k * 24 + c); }
-            }
+        for (int r = 0; r < NSLOT; r++) {
+            if (s_kc[r] < 0) continue;
+            if (fin(s_dl[r])) { lam_l[r] = fma(alpha, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
+            if (fin(s_du[r])) { lam_u[r] = fma(alpha, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
         }
+        __syncthreads();
     }
     if (qstatus == 1 && !(res_g <= 1e4 * tol_g && res_b <= 1e4 * tol_b && res_d <= 1e4 * tol_d && res_m <= 1e4 * tol_m)) qstatus = 4;
 
@@ -503,41 +588,58 @@ __global__ __launch_bounds__(64) void k_qp_lane(QpArgs a)
     int st = 0;
     if (qstatus == 3) st = 1;
     else if (qstatus == 2 || qstatus == 4) st = 4;
+    __syncthreads();
     if (st == 0) {
-        bool bad = false;
-        for (int e = 0; e < NS * 10; e++) bad |= !isfinite(AT(z, e));
-        if (bad) st = 1;
+        double bad = 0.0;
+        for (int e = lane; e < NS * 10; e += 64) bad = fmax(bad, isfinite(z[e]) ? 0.0 : 1.0);
+        if (wave_max(bad) > 0.0) st = 1;
     }
+    double *xw = a.x + (size_t)b * NS * 8, *uw = a.u + (size_t)b * N * 2;
     if (st == 0) {
-        for (int k = 0; k <= N; k++) {
+        for (int e = lane; e < NS * 10; e += 64) {
+            const int k = e / 10, j = e % 10;
+            if (j < 8) xw[k * 8 + j] += z[e];
+            else if (k < N) uw[k * 2 + j - 8] += z[e];
+        }
+        for (int e = lane; e < NS * 8; e += 64) pib[e] = (e < 8) ? 0.0 : pi[e];
+        for (int e = lane; e < NS * 24; e += 64) lamb[e] = 0.0;
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 8; i++) AT(x, k * 8 + i) += AT(z, k * 10 + i);
-            if (k < N) { AT(u, k * 2 + 0) += AT(z, k * 10 + 8); AT(u, k * 2 + 1) += AT(z, k * 10 + 9); }
-#pragma unroll
-            for (int i = 0; i < 8; i++) AT(pi, k * 8 + i) = (k == 0) ? 0.0 : AT(qpi, k * 8 + i);
-#pragma unroll
-            for (int c = 0; c < 24; c++) AT(lam, k * 24 + c) = AT(qlam, k * 24 + c);
+        for (int r = 0; r < NSLOT; r++) {
+            if (s_kc[r] < 0) continue;
+            const int k = s_kc[r] / 12, c = s_kc[r] % 12;
+            lamb[k * 24 + c] = lam_l[r];
+            lamb[k * 24 + 12 + c] = lam_u[r];
         }
     }
-    AT(u0, 0) = AT(u, 0);
-    AT(u0, 1) = AT(u, 1);
-    a.status[b] = st;
-    a.qp_iter[b] = it;
+    __syncthreads();
+    if (lane < 2) a.u0[(size_t)b * 2 + lane] = uw[lane];
+    if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; }
 }
 
 }  // namespace
 
-void ihm2_launch_qp(ihm2mpc_handle *h)
+int ihm2_launch_qp(ihm2mpc_handle *h)
 {
     QpArgs a;
-    a.B = h->B; a.Bp = h->Bp; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max;
+    a.B = h->B; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max; a.nslots = h->nslots; a.m_act = h->m_act;
     a.tol = h->cfg.ipm_tol; a.mu0 = h->cfg.ipm_mu0; a.tau0 = h->cfg.ipm_tau0;
-    a.Hs = h->Hs; a.Gy = h->Gy; a.lbx = h->lbx; a.ubx = h->ubx; a.lbu = h->lbu; a.ubu = h->ubu; a.CD = h->CD; a.lg = h->lg; a.ug = h->ug;
+    a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.A = h->A; a.Bm = h->Bm; a.bvec = h->bvec;
-    a.g = h->q_g; a.dl = h->q_dl; a.du = h->q_du; a.z = h->q_z; a.qpi = h->q_pi; a.qlam = h->q_lam; a.qt = h->q_t;
-    a.gt = h->q_gt; a.rb = h->q_rb; a.rd = h->q_rd; a.dz = h->q_dz; a.dpi = h->q_dpi; a.dlam = h->q_dlam; a.dt = h->q_dt;
-    a.dlam_a = h->q_dlam_a; a.dt_a = h->q_dt_a; a.P = h->q_P; a.Gux = h->q_Gux; a.Ginv = h->q_Ginv; a.p = h->q_p; a.kff = h->q_kff;
-    hipLaunchKernelGGL(k_qp_lane, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, a);
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P;
+    const int N = h->N, NS = h->NS;
+    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 12) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 64 + 80 + 80 + 100 + 8 + 12 + 8 + 4);
+    if (lds > 160 * 1024) return 1;
+    const int per_lane = (h->nslots + 63) / 64;
+    if (per_lane <= 5) {
+        (void)hipFuncSetAttribute((const void *)k_qp_wave<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_qp_wave<5>, dim3(h->B), dim3(64), lds, h->stream, a);
+    } else if (per_lane <= 8) {
+        (void)hipFuncSetAttribute((const void *)k_qp_wave<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_qp_wave<8>, dim3(h->B), dim3(64), lds, h->stream, a);
+    } else {
+        return 2;
+    }
+    return 0;
 }
