@@ -11,11 +11,11 @@
 // forward sweep).  Tolerances are relative to sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
 //
 // Mapping: ONE WAVEFRONT PER INSTANCE (block = 64 lanes).
-//   * iterate z, pi, the modified gradient, Riccati vectors and gains: LDS (about 39 KB at N = 40);
+//   * the whole working set of the interior-point loop is LDS-resident (about 79 KB at N = 40, two
+//     instances per CU): linearisation records [A|B|b], iterate z, pi, modified gradient, Riccati
+//     matrices P_k (packed symmetric), vectors and gains -- HBM is touched once to load and once to store;
 //   * multipliers / slacks / their steps: registers, each lane owns NSLOT two-sided constraint slots
 //     (320 slots at the reference's dimensions = 5 per lane);
-//   * per-stage records [A|B|b] (704 B) and P_k (512 B): one coalesced wave access each from HBM/L2,
-//     prefetched one stage ahead of the sequential sweeps;
 //   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands read from LDS (broadcast rows,
 //     consecutive columns: conflict-free), wave reductions by cross-lane shuffles.
 #include "ihm2mpc_internal.h"
@@ -34,10 +34,20 @@ struct QpArgs {
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g, *P;
+    double *g;
 };
 
 #define INF_BOUND 1e20
+
+// The block is ONE wavefront: its lanes run in lockstep and the LDS serves one wave's instructions in
+// order, so a hand-off through LDS needs no s_barrier -- only a compiler fence.  (A __syncthreads()
+// would also drain vmcnt(0), i.e. stall every phase on the prefetches and P_k stores in flight.)
+#define WSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
 
 __device__ __forceinline__ bool fin(double v) { return fabs(v) < INF_BOUND; }
 
@@ -66,6 +76,12 @@ __device__ __forceinline__ double wave_nanmax(double v)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = nanmax(v, __shfl_xor(v, o));
     return v;
+}
+
+__device__ __forceinline__ int sym8(int i, int j)
+{
+    const int r = min(i, j), c = max(i, j);
+    return r * 8 - (r * (r - 1)) / 2 + (c - r);
 }
 
 // upper-triangle enumeration of a 10x10 symmetric matrix: entry e in [0,55) -> (i <= j)
@@ -106,16 +122,20 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *hs = Gs + 100;           // 8
     double *gz = hs + 8;             // 10 (+2 pad)
     double *dxs = gz + 12;           // 8
-    double *dus = dxs + 8;           // 2 (+2 pad)
+    double *dus = dxs + 16;          // 2 (+2 pad)   (dxs is double-buffered: 2 x 8)
+    double *ABl = dus + 4;           // N*88  linearisation records [A | B | b], LDS-resident
+    double *Pl = ABl + N * LIN_REC;  // NS*36 Riccati matrices, packed upper triangle
     double *dz = bufA;
 
     const double *xb = a.x + (size_t)b * NS * 8;
     const double *ub = a.u + (size_t)b * N * 2;
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
     double *gb = a.g + (size_t)b * NS * 10;
-    double *Pb = a.P + (size_t)b * NS * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 24;
+
+    for (int e = lane; e < N * LIN_REC; e += 64) ABl[e] = linb[e];
+    WSYNC();
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         // stationarity: g + AB' pi_{k+1} - [pi_k;0] - R'(lam_l - lam_u)
         double st = acc;
         if (k < N) {
-            const double *rec = linb + (size_t)k * LIN_REC;
+            const double *rec = ABl + k * LIN_REC;
 #pragma unroll
             for (int l = 0; l < 8; l++) st = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pib[(k + 1) * 8 + l], st);
         }
@@ -155,7 +175,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (counted) r_stat = fmax(r_stat, fabs(st));
     }
     for (int e = lane; e < N * 8; e += 64) {
-        const double bl = linb[(size_t)(e / 8) * LIN_REC + 80 + (e % 8)];
+        const double bl = ABl[(e / 8) * LIN_REC + 80 + (e % 8)];
         sb = fmax(sb, fabs(bl));
         r_eq = fmax(r_eq, fabs(bl));
     }
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     // ------------------------------------------------------------------ initial point
     for (int e = lane; e < NS * 10; e += 64) z[e] = (e < 8) ? a.x0[(size_t)b * 8 + e] - xb[e] : 0.0;
     for (int e = lane; e < NS * 8; e += 64) pi[e] = 0.0;
-    __syncthreads();
+    WSYNC();
 #pragma unroll
     for (int r = 0; r < NSLOT; r++) {
         if (s_kc[r] < 0) continue;
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             Rz[e] = v;
             bufA[e] = 0.0;
         }
-        __syncthreads();
+        WSYNC();
         double mu_acc = 0.0;
         res_d = 0.0; res_m = 0.0;
 #pragma unroll
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             res_d = nanmax(res_d, nanmax(fabs(rd_l[r]), fabs(rd_u[r])));
             bufA[s_kc[r]] = lam_l[r] - lam_u[r];
         }
-        __syncthreads();
+        WSYNC();
         // ---- stationarity and dynamics residuals ----
         res_g = 0.0; res_b = 0.0;
         for (int e = lane; e < NS * 10; e += 64) {
@@ -269,7 +289,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 #pragma unroll
             for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
             if (k < N) {
-                const double *rec = linb + (size_t)k * LIN_REC;
+                const double *rec = ABl + k * LIN_REC;
 #pragma unroll
                 for (int l = 0; l < 8; l++) acc = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pi[(k + 1) * 8 + l], acc);
                 acc = fma(-a.CD[(k * 2 + 0) * 10 + j], bufA[k * 12 + 10], acc);
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         }
         for (int e = lane; e < N * 8; e += 64) {
             const int k = e / 8, i = e % 8;
-            const double *rec = linb + (size_t)k * LIN_REC;
+            const double *rec = ABl + k * LIN_REC;
             double acc = rec[80 + i] - z[(k + 1) * 10 + i];
 #pragma unroll
             for (int l = 0; l < 8; l++) acc = fma(rec[i * 8 + l], z[k * 10 + l], acc);
@@ -297,13 +317,13 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; }
         if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; }
         if (it >= a.iter_max) { qstatus = 1; break; }
-        __syncthreads();
+        WSYNC();
 
         double alpha = 1.0, sigma = 0.0;
         for (int pass = 0; pass < 2; pass++) {
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
             for (int e = lane; e < NS * 12; e += 64) { bufA[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
-            __syncthreads();
+            WSYNC();
             const double mu_t = fmax(sigma * mu, mu_floor);
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
@@ -320,7 +340,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 }
                 bufA[s_kc[r]] = cf;
             }
-            __syncthreads();
+            WSYNC();
             for (int e = lane; e < NS * 10; e += 64) {
                 const int k = e / 10, j = e % 10;
                 double acc = gt[e] + bufA[k * 12 + j];
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 }
                 gt[e] = acc;        // pass 1 adds its increment on top of the predictor's gradient
             }
-            __syncthreads();
+            WSYNC();
 
             // ---- backward Riccati sweep ----
             if (pass == 0) {
@@ -339,34 +359,38 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     double v = a.Hs[(N * 10 + i) * 10 + j];
                     if (i == j) v += gam[N * 12 + i];
                     Pn[lane] = v;
-                    Pb[(size_t)N * 64 + lane] = v;
+                    if (i <= j) Pl[N * 36 + sym8(i, j)] = v;
                     if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
                 }
-                // prefetch the record of stage N-1
-                double regA = linb[(size_t)(N - 1) * LIN_REC + lane];
-                double regB = (lane < 16) ? linb[(size_t)(N - 1) * LIN_REC + 64 + lane] : 0.0;
-                __syncthreads();
+                // this lane's entry of the stage Hessian / general rows, prefetched one stage ahead
+                int gi = 0, gj = 0;
+                if (lane < 55) sym10_ij(lane, gi, gj);
+                const int ci = (gi < 8) ? gi : 64 + (gi - 8), si = (gi < 8) ? 8 : 2;      // column gi of [A B] in a record
+                double regH = a.Hs[((N - 1) * 10 + gi) * 10 + gj];
+                double rc0i = a.CD[((N - 1) * 2 + 0) * 10 + gi], rc0j = a.CD[((N - 1) * 2 + 0) * 10 + gj];
+                double rc1i = a.CD[((N - 1) * 2 + 1) * 10 + gi], rc1j = a.CD[((N - 1) * 2 + 1) * 10 + gj];
+                WSYNC();
                 for (int k = N - 1; k >= 0; k--) {
-                    ABs[(lane >> 3) * 10 + (lane & 7)] = regA;
-                    if (lane < 16) ABs[(lane >> 1) * 10 + 8 + (lane & 1)] = regB;
+                    const double *AB = ABl + k * LIN_REC;
+                    const double Hk = regH, c0i = rc0i, c0j = rc0j, c1i = rc1i, c1j = rc1j;
                     if (k > 0) {
-                        regA = linb[(size_t)(k - 1) * LIN_REC + lane];
-                        if (lane < 16) regB = linb[(size_t)(k - 1) * LIN_REC + 64 + lane];
+                        regH = a.Hs[((k - 1) * 10 + gi) * 10 + gj];
+                        rc0i = a.CD[((k - 1) * 2 + 0) * 10 + gi]; rc0j = a.CD[((k - 1) * 2 + 0) * 10 + gj];
+                        rc1i = a.CD[((k - 1) * 2 + 1) * 10 + gi]; rc1j = a.CD[((k - 1) * 2 + 1) * 10 + gj];
                     }
-                    __syncthreads();
-                    // W = P_{k+1} [A B]  (80 entries) ; h = P_{k+1} rb_k + p_{k+1}
+                    // W = P_{k+1} [A B]  (64 + 16 entries) ; h = P_{k+1} rb_k + p_{k+1}
                     {
-                        const int i = lane / 10, j = lane % 10;      // entries 0..63
+                        const int i = lane >> 3, j = lane & 7;
                         double acc = 0.0;
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(Pn[i * 8 + l], ABs[l * 10 + j], acc);
-                        Ws[lane] = acc;
+                        for (int l = 0; l < 8; l++) acc = fma(Pn[i * 8 + l], AB[l * 8 + j], acc);
+                        Ws[i * 10 + j] = acc;
                         if (lane < 16) {
-                            const int e2 = 64 + lane, i2 = e2 / 10, j2 = e2 % 10;
+                            const int i2 = lane >> 1, j2 = lane & 1;
                             double acc2 = 0.0;
 #pragma unroll
-                            for (int l = 0; l < 8; l++) acc2 = fma(Pn[i2 * 8 + l], ABs[l * 10 + j2], acc2);
-                            Ws[e2] = acc2;
+                            for (int l = 0; l < 8; l++) acc2 = fma(Pn[i2 * 8 + l], AB[64 + l * 2 + j2], acc2);
+                            Ws[i2 * 10 + 8 + j2] = acc2;
                         } else if (lane < 24) {
                             const int i2 = lane - 16;
                             double acc2 = 0.0;
@@ -376,27 +400,26 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                             hs[i2] = acc2 + pv[(k + 1) * 8 + i2];
                         }
                     }
-                    __syncthreads();
+                    WSYNC();
                     // G = Ht + [A B]' W  (upper triangle, 55 entries) ; gz = gt_k + [A B]' h
                     if (lane < 55) {
-                        int i, j;
-                        sym10_ij(lane, i, j);
-                        double acc = a.Hs[(k * 10 + i) * 10 + j];
-                        if (i == j) acc += gam[k * 12 + i];
-                        acc = fma(gam[k * 12 + 10] * a.CD[(k * 2 + 0) * 10 + i], a.CD[(k * 2 + 0) * 10 + j], acc);
-                        acc = fma(gam[k * 12 + 11] * a.CD[(k * 2 + 1) * 10 + i], a.CD[(k * 2 + 1) * 10 + j], acc);
+                        double acc = Hk;
+                        if (gi == gj) acc += gam[k * 12 + gi];
+                        acc = fma(gam[k * 12 + 10] * c0i, c0j, acc);
+                        acc = fma(gam[k * 12 + 11] * c1i, c1j, acc);
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(ABs[l * 10 + i], Ws[l * 10 + j], acc);
-                        Gs[i * 10 + j] = acc;
-                        Gs[j * 10 + i] = acc;
+                        for (int l = 0; l < 8; l++) acc = fma(AB[ci + l * si], Ws[l * 10 + gj], acc);
+                        Gs[gi * 10 + gj] = acc;
+                        Gs[gj * 10 + gi] = acc;
                     }
                     if (lane < 10) {
+                        const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
                         double acc = gt[k * 10 + lane];
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(ABs[l * 10 + lane], hs[l], acc);
+                        for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], hs[l], acc);
                         gz[lane] = acc;
                     }
-                    __syncthreads();
+                    WSYNC();
                     // P_k = Gxx - Gux' Guu^-1 Gux ; gains ; p_k
                     {
                         const double g00 = Gs[88], g01 = Gs[89], g11 = Gs[99];
@@ -407,118 +430,89 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                         const double ai = Gs[i * 10 + 8], bi = Gs[i * 10 + 9], cj = Gs[j * 10 + 8], dj = Gs[j * 10 + 9];
                         const double v = Gs[i * 10 + j] - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
                         Pn[lane] = v;
-                        Pb[(size_t)k * 64 + lane] = v;
+                        if (i0 <= j0) Pl[k * 36 + sym8(i0, j0)] = v;
                         if (lane < 16) Gux[k * 16 + lane] = Gs[(lane & 7) * 10 + 8 + (lane >> 3)];
                         if (lane == 0) { Ginv[k * 4 + 0] = Gi0; Ginv[k * 4 + 1] = Gi1; Ginv[k * 4 + 2] = Gi2; }
                         const double kf0 = Gi0 * gz[8] + Gi1 * gz[9], kf1 = Gi1 * gz[8] + Gi2 * gz[9];
                         if (lane < 2) kff[k * 2 + lane] = lane ? kf1 : kf0;
                         if (lane < 8) pv[k * 8 + lane] = gz[lane] - (Gs[lane * 10 + 8] * kf0 + Gs[lane * 10 + 9] * kf1);
                     }
-                    __syncthreads();
+                    WSYNC();
                 }
             } else {
-                // vector-only sweep with the stored factorisation: lanes 0..9 hold column `lane` of [A B]_k
+                // vector-only sweep with the stored factorisation
                 if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
-                double col[8];
-#pragma unroll
-                for (int l = 0; l < 8; l++)
-                    col[l] = (lane < 8) ? linb[(size_t)(N - 1) * LIN_REC + l * 8 + lane]
-                                        : ((lane < 10) ? linb[(size_t)(N - 1) * LIN_REC + 64 + l * 2 + (lane - 8)] : 0.0);
-                __syncthreads();
+                const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
+                WSYNC();
                 for (int k = N - 1; k >= 0; k--) {
+                    const double *AB = ABl + k * LIN_REC;
                     if (lane < 10) {
                         double acc = gt[k * 10 + lane];
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(col[l], Prb[k * 8 + l] + pv[(k + 1) * 8 + l], acc);
+                        for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], Prb[k * 8 + l] + pv[(k + 1) * 8 + l], acc);
                         gz[lane] = acc;
                     }
-                    if (k > 0) {
-#pragma unroll
-                        for (int l = 0; l < 8; l++)
-                            col[l] = (lane < 8) ? linb[(size_t)(k - 1) * LIN_REC + l * 8 + lane]
-                                                : ((lane < 10) ? linb[(size_t)(k - 1) * LIN_REC + 64 + l * 2 + (lane - 8)] : 0.0);
-                    }
-                    __syncthreads();
+                    WSYNC();
                     {
                         const double Gi0 = Ginv[k * 4 + 0], Gi1 = Ginv[k * 4 + 1], Gi2 = Ginv[k * 4 + 2];
                         const double kf0 = Gi0 * gz[8] + Gi1 * gz[9], kf1 = Gi1 * gz[8] + Gi2 * gz[9];
                         if (lane < 2) kff[k * 2 + lane] = lane ? kf1 : kf0;
                         if (lane < 8) pv[k * 8 + lane] = gz[lane] - (Gux[k * 16 + lane] * kf0 + Gux[k * 16 + 8 + lane] * kf1);
                     }
-                    __syncthreads();
+                    WSYNC();
                 }
             }
 
             // ---- forward sweep: dz (into bufA), dpi (into pv, corrector pass or no inequalities) ----
             const bool want_dpi = (pass == 1) || (a.m_act == 0);
             if (lane < 8) dxs[lane] = 0.0;
-            // lanes 0..7: row `lane` of [A B]_k ; lanes 8..15: row lane-8 of P_k (when dpi is wanted)
-            double row[10];
-#pragma unroll
-            for (int l = 0; l < 10; l++) row[l] = 0.0;
-            if (lane < 8) {
-#pragma unroll
-                for (int l = 0; l < 8; l++) row[l] = linb[lane * 8 + l];
-                row[8] = linb[64 + lane * 2]; row[9] = linb[64 + lane * 2 + 1];
-            } else if (lane < 16 && want_dpi) {
-#pragma unroll
-                for (int l = 0; l < 8; l++) row[l] = Pb[(lane - 8) * 8 + l];
-            }
-            __syncthreads();
+            WSYNC();
             for (int k = 0; k < N; k++) {
+                const double *AB = ABl + k * LIN_REC;
+                const double *dxc = dxs + (k & 1) * 8;
                 if (lane < 2) {
                     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) { t0 = fma(Gux[k * 16 + j], dxs[j], t0); t1 = fma(Gux[k * 16 + 8 + j], dxs[j], t1); }
+                    for (int j = 0; j < 8; j++) { t0 = fma(Gux[k * 16 + j], dxc[j], t0); t1 = fma(Gux[k * 16 + 8 + j], dxc[j], t1); }
                     const double Gi0 = Ginv[k * 4 + 0], Gi1 = Ginv[k * 4 + 1], Gi2 = Ginv[k * 4 + 2];
                     const double du = lane ? (-(Gi1 * t0 + Gi2 * t1) - kff[k * 2 + 1]) : (-(Gi0 * t0 + Gi1 * t1) - kff[k * 2 + 0]);
                     dus[lane] = du;
                     dz[k * 10 + 8 + lane] = du;
                 } else if (lane >= 8 && lane < 16) {
                     if (want_dpi) {
-                        double acc = pv[k * 8 + lane - 8];
+                        const int i = lane - 8;
+                        double acc = pv[k * 8 + i];
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(row[l], dxs[l], acc);
-                        pv[k * 8 + lane - 8] = acc;        // dpi_k
+                        for (int l = 0; l < 8; l++) acc = fma(Pl[k * 36 + sym8(i, l)], dxc[l], acc);
+                        pv[k * 8 + i] = acc;        // dpi_k
                     }
                 } else if (lane >= 16 && lane < 24) {
-                    dz[k * 10 + lane - 16] = dxs[lane - 16];
+                    dz[k * 10 + lane - 16] = dxc[lane - 16];
                 }
-                __syncthreads();
-                double dxn = 0.0;
+                WSYNC();
                 if (lane < 8) {
-                    dxn = rb[k * 8 + lane];
+                    double dxn = rb[k * 8 + lane];
 #pragma unroll
-                    for (int l = 0; l < 8; l++) dxn = fma(row[l], dxs[l], dxn);
-                    dxn = fma(row[8], dus[0], dxn);
-                    dxn = fma(row[9], dus[1], dxn);
+                    for (int l = 0; l < 8; l++) dxn = fma(AB[lane * 8 + l], dxc[l], dxn);
+                    dxn = fma(AB[64 + lane * 2 + 0], dus[0], dxn);
+                    dxn = fma(AB[64 + lane * 2 + 1], dus[1], dxn);
+                    dxs[((k + 1) & 1) * 8 + lane] = dxn;
                 }
-                // prefetch the rows of the next stage
-                if (lane < 8) {
-                    if (k + 1 < N) {
-                        const double *rec = linb + (size_t)(k + 1) * LIN_REC;
+                WSYNC();
+            }
+            {
+                const double *dxc = dxs + (N & 1) * 8;
+                if (lane < 8) { dz[N * 10 + lane] = dxc[lane]; }
+                else if (lane < 10) { dz[N * 10 + lane] = 0.0; }
+                else if (lane >= 16 && lane < 24 && want_dpi) {
+                    const int i = lane - 16;
+                    double acc = pv[N * 8 + i];
 #pragma unroll
-                        for (int l = 0; l < 8; l++) row[l] = rec[lane * 8 + l];
-                        row[8] = rec[64 + lane * 2]; row[9] = rec[64 + lane * 2 + 1];
-                    }
-                } else if (lane < 16 && want_dpi) {
-#pragma unroll
-                    for (int l = 0; l < 8; l++) row[l] = Pb[(size_t)(k + 1) * 64 + (lane - 8) * 8 + l];
+                    for (int l = 0; l < 8; l++) acc = fma(Pl[N * 36 + sym8(i, l)], dxc[l], acc);
+                    pv[N * 8 + i] = acc;
                 }
-                __syncthreads();
-                if (lane < 8) dxs[lane] = dxn;
-                __syncthreads();
             }
-            if (lane < 8) { dz[N * 10 + lane] = dxs[lane]; }
-            else if (lane < 10) { dz[N * 10 + lane] = 0.0; }
-            else if (lane >= 16 && lane < 24 && want_dpi) {
-                const int i = lane - 16;
-                double acc = pv[N * 8 + i];
-#pragma unroll
-                for (int l = 0; l < 8; l++) acc = fma(Pb[(size_t)N * 64 + i * 8 + l], dxs[l], acc);
-                pv[N * 8 + i] = acc;
-            }
-            __syncthreads();
+            WSYNC();
 
             // ---- R dz, slack / multiplier steps, step length ----
             for (int e = lane; e < NS * 12; e += 64) {
@@ -531,7 +525,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 }
                 Rz[e] = v;
             }
-            __syncthreads();
+            WSYNC();
             double amax = 1.0, mu_aff = 0.0;
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
@@ -569,7 +563,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             } else {
                 alpha = fmin(1.0, 0.995 * amax);
             }
-            __syncthreads();
+            WSYNC();
         }
         if (alpha < 1e-12) { qstatus = 2; break; }
         for (int e = lane; e < NS * 10; e += 64) z[e] = fma(alpha, dz[e], z[e]);
@@ -580,7 +574,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             if (fin(s_dl[r])) { lam_l[r] = fma(alpha, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
             if (fin(s_du[r])) { lam_u[r] = fma(alpha, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
         }
-        __syncthreads();
+        WSYNC();
     }
     if (qstatus == 1 && !(res_g <= 1e4 * tol_g && res_b <= 1e4 * tol_b && res_d <= 1e4 * tol_d && res_m <= 1e4 * tol_m)) qstatus = 4;
 
@@ -588,7 +582,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     int st = 0;
     if (qstatus == 3) st = 1;
     else if (qstatus == 2 || qstatus == 4) st = 4;
-    __syncthreads();
+    WSYNC();
     if (st == 0) {
         double bad = 0.0;
         for (int e = lane; e < NS * 10; e += 64) bad = fmax(bad, isfinite(z[e]) ? 0.0 : 1.0);
@@ -603,7 +597,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         }
         for (int e = lane; e < NS * 8; e += 64) pib[e] = (e < 8) ? 0.0 : pi[e];
         for (int e = lane; e < NS * 24; e += 64) lamb[e] = 0.0;
-        __syncthreads();
+        WSYNC();
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
@@ -612,7 +606,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             lamb[k * 24 + 12 + c] = lam_u[r];
         }
     }
-    __syncthreads();
+    WSYNC();
     if (lane < 2) a.u0[(size_t)b * 2 + lane] = uw[lane];
     if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; }
 }
@@ -627,9 +621,9 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P;
+    a.lin = h->lin; a.g = h->q_g;
     const int N = h->N, NS = h->NS;
-    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 12) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 64 + 80 + 80 + 100 + 8 + 12 + 8 + 4);
+    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 12 + 36) + (size_t)N * (8 + 2 + 16 + 4 + 8 + LIN_REC) + 64 + 80 + 80 + 100 + 8 + 12 + 16 + 4);
     if (lds > 160 * 1024) return 1;
     const int per_lane = (h->nslots + 63) / 64;
     if (per_lane <= 5) {

@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch, each solves its own block (here with the CPU
+oracle standing in for the device), one all_gather reassembles the results in global order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from ihm2_amd.dist import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition():
+    for total in (1, 7, 64, 1000, 65536):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(total, world, r) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="2")
+    import torch
+    import torch.distributed as dist
+    from conftest import make_ocp, sample_x0
+
+    from ihm2_amd.dist import all_gather_blocks, shard
+    from ihm2_amd.track import track_table
+    from oracle import oracle as orc
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    track = track_table("fsds_competition_1")
+    N = 10
+    P = orc.OracleProblem(make_ocp(N=N, M=20).flatten().as_dict(track.s_ref, track.kappa_ref))
+    x0_all = sample_x0(track, total, seed=3)
+    x0 = shard(x0_all, world, rank)
+    B = x0.shape[0]
+    x = np.repeat(x0[:, None, :], N + 1, axis=1).copy(); u = np.zeros((B, N, 2))
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 10.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 10.0
+    out = P.rti_step(x, u, x0, yref, yref_e, nthreads=2)
+    u0 = all_gather_blocks(torch.from_numpy(u[:, 0].copy()), total)
+    st = all_gather_blocks(torch.from_numpy(out["status"].astype(np.int32)), total)
+    dist.barrier()
+    if rank == 0:
+        q.put((u0.numpy(), st.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shard_and_gather(track):
+    import torch.multiprocessing as mp
+    from conftest import make_ocp, sample_x0
+
+    from oracle import oracle as orc
+
+    total, world = 11, 2          # uneven split: 6 + 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    u0, st = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the whole batch
+    N = 10
+    P = orc.OracleProblem(make_ocp(N=N, M=20).flatten().as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, total, seed=3)
+    x = np.repeat(x0[:, None, :], N + 1, axis=1).copy(); u = np.zeros((total, N, 2))
+    yref = np.zeros((total, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 10.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((total, 8)); yref_e[:, 0] = x0[:, 0] + 10.0
+    out = P.rti_step(x, u, x0, yref, yref_e, nthreads=2)
+    np.testing.assert_array_equal(st, out["status"])
+    np.testing.assert_allclose(u0, u[:, 0], rtol=1e-12, atol=1e-12)
