@@ -7,17 +7,24 @@
 //        lb - c(z) <= R_k z_k <= ub - c(z)   (8 state boxes, 2 input boxes, 2 general rows [C D])
 // H_k = cost_scale * V'W_kV is constant and shared by the batch (python/mpc.py:49-64); g_k = H_k z_k - Gy_k yref_k.
 // Solver: Mehrotra predictor-corrector primal-dual interior point; the Newton system is reduced to
-// an equality-constrained LQ problem solved by a Riccati recursion (backward factor+vector sweep,
-// forward sweep).  Tolerances are relative to sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
+// an equality-constrained LQ problem solved by a Riccati recursion.  Tolerances are relative to
+// sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
 //
-// Mapping: ONE WAVEFRONT PER INSTANCE (block = 64 lanes).
-//   * the whole working set of the interior-point loop is LDS-resident (about 79 KB at N = 40, two
-//     instances per CU): linearisation records [A|B|b], iterate z, pi, modified gradient, Riccati
-//     matrices P_k (packed symmetric), vectors and gains -- HBM is touched once to load and once to store;
-//   * multipliers / slacks / their steps: registers, each lane owns NSLOT two-sided constraint slots
-//     (320 slots at the reference's dimensions = 5 per lane);
-//   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands read from LDS (broadcast rows,
-//     consecutive columns: conflict-free), wave reductions by cross-lane shuffles.
+// Mapping: ONE WAVEFRONT PER INSTANCE (block = 64 lanes), 4 instances per CU (38.5 KB of LDS each).
+//   * LDS: iterate z, pi, modified gradient, dynamics residual, Riccati vectors p_k, gains K_k, step dz.
+//   * registers: multipliers / slacks / their steps -- each lane owns NSLOT two-sided constraint slots
+//     (320 slots at the reference's dimensions = 5 per lane).
+//   * HBM/L2: linearisation records [A|B|b] (704 B per stage) are STREAMED through a two-slot LDS
+//     staging buffer by a register ring that runs four stages ahead of each sequential sweep (one
+//     coalesced wave load per record); P_k (512 B) is stored once per factorisation, read back in a
+//     fully parallel phase.
+//   * the three sequential recursions are one LDS hop per stage each:
+//       factor   P_k = Gxx - Gux' Guu^-1 Gux          (three hops: W = P[A B], G = H~ + [A B]'W, P/K)
+//       vector   p_k = gt_x - K'gt_u + (A - B K)'(P_{k+1} rb_k + p_{k+1})
+//       forward  dx_{k+1} = rb_k - B kff_k + (A - B K) dx_k
+//     with kff_k, du_k and dpi_k recovered afterwards in parallel over all stages.
+//   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands from LDS (row reads broadcast,
+//     column reads consecutive: conflict-free); wave reductions by cross-lane shuffles.
 #include "ihm2mpc_internal.h"
 
 namespace {
@@ -34,14 +41,14 @@ struct QpArgs {
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g;
+    double *g, *P;
 };
 
 #define INF_BOUND 1e20
 
 // The block is ONE wavefront: its lanes run in lockstep and the LDS serves one wave's instructions in
 // order, so a hand-off through LDS needs no s_barrier -- only a compiler fence.  (A __syncthreads()
-// would also drain vmcnt(0), i.e. stall every phase on the prefetches and P_k stores in flight.)
+// would also drain vmcnt(0), i.e. stall every phase on the record prefetches and P_k stores in flight.)
 #define WSYNC()                                                  \
     do {                                                         \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
@@ -78,12 +85,6 @@ __device__ __forceinline__ double wave_nanmax(double v)
     return v;
 }
 
-__device__ __forceinline__ int sym8(int i, int j)
-{
-    const int r = min(i, j), c = max(i, j);
-    return r * 8 - (r * (r - 1)) / 2 + (c - r);
-}
-
 // upper-triangle enumeration of a 10x10 symmetric matrix: entry e in [0,55) -> (i <= j)
 __device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
 {
@@ -92,6 +93,46 @@ __device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
     for (int q = 0; q < 9; q++)
         if (r == q && rem >= 10 - q) { rem -= 10 - q; r = q + 1; }
     i = r; j = r + rem;
+}
+
+// Sequential sweep over the stages with the linearisation records streamed from HBM/L2.
+// DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  A register ring holds the next four records (lane e
+// keeps elements e and 64+e of each); the record of the next stage is written to the other LDS slot at
+// the top of a stage, so the loads are consumed >= 3 stages after they were issued.
+// body(k, rec) must end with WSYNC().
+template <int DIR, typename F>
+__device__ __forceinline__ void stream_sweep(const double *linb, double *stage2, int N, int lane, F &&body)
+{
+    double ra[4], rb2[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int kk = (DIR < 0) ? N - 1 - d : d;
+        const bool ok = d < N;
+        ra[d] = ok ? linb[(size_t)kk * LIN_REC + lane] : 0.0;
+        rb2[d] = (ok && lane < 24) ? linb[(size_t)kk * LIN_REC + 64 + lane] : 0.0;
+    }
+    stage2[lane] = ra[0];
+    if (lane < 24) stage2[64 + lane] = rb2[0];
+    WSYNC();
+    for (int s0 = 0; s0 < N; s0 += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int s = s0 + d;
+            if (s >= N) break;
+            const int k = (DIR < 0) ? N - 1 - s : s;
+            double *cur = stage2 + (s & 1) * LIN_REC, *nxt = stage2 + ((s + 1) & 1) * LIN_REC;
+            if (s + 1 < N) {
+                nxt[lane] = ra[(d + 1) & 3];
+                if (lane < 24) nxt[64 + lane] = rb2[(d + 1) & 3];
+            }
+            if (s + 4 < N) {
+                const int kk = (DIR < 0) ? N - 1 - (s + 4) : s + 4;
+                ra[d] = linb[(size_t)kk * LIN_REC + lane];
+                if (lane < 24) rb2[d] = linb[(size_t)kk * LIN_REC + 64 + lane];
+            }
+            body(k, cur);
+        }
+    }
 }
 
 template <int NSLOT>
@@ -106,36 +147,27 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *z = sm;                  // NS*10  QP iterate
     double *gt = z + NS * 10;        // NS*10  stationarity residual / modified gradient
     double *pi = gt + NS * 10;       // NS*8   QP costates
-    double *pv = pi + NS * 8;        // NS*8   Riccati vector p_k, overwritten by dpi_k in the last forward sweep
+    double *pv = pi + NS * 8;        // NS*8   Riccati vector p_k, then dpi_k
     double *rb = pv + NS * 8;        // N*8    dynamics residual
-    double *Rz = rb + N * 8;         // NS*12  R z (then R dz)
-    double *bufA = Rz + NS * 12;     // NS*12  lam_l - lam_u / gradient coefficients / dz (NS*10)
-    double *gam = bufA + NS * 12;    // NS*12  barrier weights
-    double *kff = gam + NS * 12;     // N*2
-    double *Gux = kff + N * 2;       // N*16
-    double *Ginv = Gux + N * 16;     // N*4 (3 used)
-    double *Prb = Ginv + N * 4;      // N*8   P_{k+1} rb_k (same for predictor and corrector)
-    double *Pn = Prb + N * 8;        // 64
-    double *ABs = Pn + 64;           // 80   [l][10]
-    double *Ws = ABs + 80;           // 80   [l][10]
+    double *gam = rb + N * 8;        // NS*12  barrier weights per constraint slot
+    double *cf = gam + NS * 12;      // NS*12  lam_l - lam_u, then gradient coefficients
+    double *dz = cf + NS * 12;       // NS*10  step
+    double *kff = dz + NS * 10;      // N*2
+    double *Kl = kff + N * 2;        // N*16   K_k = Guu^-1 Gux
+    double *Ginv = Kl + N * 16;      // N*4    Guu^-1 (3 used)
+    double *Prb = Ginv + N * 4;      // N*8    P_{k+1} rb_k (same for predictor and corrector)
+    double *stage2 = Prb + N * 8;    // 2*88   staging slots of the streamed records
+    double *Pn = stage2 + 2 * LIN_REC; // 64   P_{k+1}
+    double *Ws = Pn + 64;            // 80     [l][10]
     double *Gs = Ws + 80;            // 100
-    double *hs = Gs + 100;           // 8
-    double *gz = hs + 8;             // 10 (+2 pad)
-    double *dxs = gz + 12;           // 8
-    double *dus = dxs + 16;          // 2 (+2 pad)   (dxs is double-buffered: 2 x 8)
-    double *ABl = dus + 4;           // N*88  linearisation records [A | B | b], LDS-resident
-    double *Pl = ABl + N * LIN_REC;  // NS*36 Riccati matrices, packed upper triangle
-    double *dz = bufA;
 
     const double *xb = a.x + (size_t)b * NS * 8;
     const double *ub = a.u + (size_t)b * N * 2;
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
     double *gb = a.g + (size_t)b * NS * 10;
+    double *Pg = a.P + (size_t)b * NS * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 24;
-
-    for (int e = lane; e < N * LIN_REC; e += 64) ABl[e] = linb[e];
-    WSYNC();
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
@@ -162,7 +194,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         // stationarity: g + AB' pi_{k+1} - [pi_k;0] - R'(lam_l - lam_u)
         double st = acc;
         if (k < N) {
-            const double *rec = ABl + k * LIN_REC;
+            const double *rec = linb + (size_t)k * LIN_REC;
 #pragma unroll
             for (int l = 0; l < 8; l++) st = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pib[(k + 1) * 8 + l], st);
         }
@@ -175,7 +207,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (counted) r_stat = fmax(r_stat, fabs(st));
     }
     for (int e = lane; e < N * 8; e += 64) {
-        const double bl = ABl[(e / 8) * LIN_REC + 80 + (e % 8)];
+        const double bl = linb[(size_t)(e / 8) * LIN_REC + 80 + (e % 8)];
         sb = fmax(sb, fabs(bl));
         r_eq = fmax(r_eq, fabs(bl));
     }
@@ -225,6 +257,16 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     const double mu0 = a.mu0 * sg;
     const double inv_m = (a.m_act > 0) ? 1.0 / a.m_act : 0.0;
 
+    // R_c . v of the slot (k, c) for a stage-major vector v[NS][10] in LDS
+    auto row_dot = [&](int kc, const double *v) -> double {
+        const int k = kc / 12, c = kc % 12;
+        if (c < 10) return v[k * 10 + c];
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 10; j++) acc = fma(a.CD[(k * 2 + c - 10) * 10 + j], v[k * 10 + j], acc);
+        return acc;
+    };
+
     // ------------------------------------------------------------------ initial point
     for (int e = lane; e < NS * 10; e += 64) z[e] = (e < 8) ? a.x0[(size_t)b * 8 + e] - xb[e] : 0.0;
     for (int e = lane; e < NS * 8; e += 64) pi[e] = 0.0;
@@ -232,15 +274,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 #pragma unroll
     for (int r = 0; r < NSLOT; r++) {
         if (s_kc[r] < 0) continue;
-        const int k = s_kc[r] / 12, c = s_kc[r] % 12;
-        double rz = 0.0;      // z = 0 except dx_0: only rows touching x at stage 0 see it
-        if (k == 0) {
-            if (c < 10) rz = z[c];
-            else {
-#pragma unroll
-                for (int j = 0; j < 10; j++) rz = fma(a.CD[(c - 10) * 10 + j], z[j], rz);
-            }
-        }
+        const double rz = row_dot(s_kc[r], z);
         const bool al = fin(s_dl[r]), au = fin(s_du[r]);
         double tau_c = a.tau0;
         if (al && au) tau_c = fmin(a.tau0, 0.25 * (s_du[r] - s_dl[r]));
@@ -254,18 +288,8 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
     double dla_l[NSLOT], dla_u[NSLOT], dta_l[NSLOT], dta_u[NSLOT];
     for (it = 0;; it++) {
-        // ---- R z ; lam_l - lam_u -> bufA ----
-        for (int e = lane; e < NS * 12; e += 64) {
-            const int k = e / 12, c = e % 12;
-            double v = 0.0;
-            if (c < 10) v = z[k * 10 + c];
-            else if (k < N) {
-#pragma unroll
-                for (int j = 0; j < 10; j++) v = fma(a.CD[(k * 2 + c - 10) * 10 + j], z[k * 10 + j], v);
-            }
-            Rz[e] = v;
-            bufA[e] = 0.0;
-        }
+        // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
+        for (int e = lane; e < NS * 12; e += 64) cf[e] = 0.0;
         WSYNC();
         double mu_acc = 0.0;
         res_d = 0.0; res_m = 0.0;
@@ -273,12 +297,12 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         for (int r = 0; r < NSLOT; r++) {
             rd_l[r] = rd_u[r] = 0.0;
             if (s_kc[r] < 0) continue;
-            const double rz = Rz[s_kc[r]];
+            const double rz = row_dot(s_kc[r], z);
             const bool al = fin(s_dl[r]), au = fin(s_du[r]);
             if (al) { rd_l[r] = rz - t_l[r] - s_dl[r]; mu_acc += lam_l[r] * t_l[r]; res_m = nanmax(res_m, fabs(lam_l[r] * t_l[r])); }
             if (au) { rd_u[r] = s_du[r] - rz - t_u[r]; mu_acc += lam_u[r] * t_u[r]; res_m = nanmax(res_m, fabs(lam_u[r] * t_u[r])); }
             res_d = nanmax(res_d, nanmax(fabs(rd_l[r]), fabs(rd_u[r])));
-            bufA[s_kc[r]] = lam_l[r] - lam_u[r];
+            cf[s_kc[r]] = lam_l[r] - lam_u[r];
         }
         WSYNC();
         // ---- stationarity and dynamics residuals ----
@@ -289,21 +313,21 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 #pragma unroll
             for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
             if (k < N) {
-                const double *rec = ABl + k * LIN_REC;
+                const double *rec = linb + (size_t)k * LIN_REC;
 #pragma unroll
                 for (int l = 0; l < 8; l++) acc = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pi[(k + 1) * 8 + l], acc);
-                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], bufA[k * 12 + 10], acc);
-                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], bufA[k * 12 + 11], acc);
+                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
+                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
             }
             if (j < 8) acc -= pi[k * 8 + j];
-            acc -= bufA[k * 12 + j];
+            acc -= cf[k * 12 + j];
             if ((k == 0 && j < 8) || (k == N && j >= 8)) acc = 0.0;
             gt[e] = acc;
             res_g = nanmax(res_g, fabs(acc));
         }
         for (int e = lane; e < N * 8; e += 64) {
             const int k = e / 8, i = e % 8;
-            const double *rec = ABl + k * LIN_REC;
+            const double *rec = linb + (size_t)k * LIN_REC;
             double acc = rec[80 + i] - z[(k + 1) * 10 + i];
 #pragma unroll
             for (int l = 0; l < 8; l++) acc = fma(rec[i * 8 + l], z[k * 10 + l], acc);
@@ -322,45 +346,44 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         double alpha = 1.0, sigma = 0.0;
         for (int pass = 0; pass < 2; pass++) {
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
-            for (int e = lane; e < NS * 12; e += 64) { bufA[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
+            for (int e = lane; e < NS * 12; e += 64) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
             WSYNC();
             const double mu_t = fmax(sigma * mu, mu_floor);
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
                 if (s_kc[r] < 0) continue;
                 const bool al = fin(s_dl[r]), au = fin(s_du[r]);
-                double cf = 0.0;
+                double c = 0.0;
                 if (pass == 0) {
-                    if (al) cf += (lam_l[r] * t_l[r] + lam_l[r] * rd_l[r]) / t_l[r];
-                    if (au) cf -= (lam_u[r] * t_u[r] + lam_u[r] * rd_u[r]) / t_u[r];
+                    if (al) c += (lam_l[r] * t_l[r] + lam_l[r] * rd_l[r]) / t_l[r];
+                    if (au) c -= (lam_u[r] * t_u[r] + lam_u[r] * rd_u[r]) / t_u[r];
                     gam[s_kc[r]] = (al ? lam_l[r] / t_l[r] : 0.0) + (au ? lam_u[r] / t_u[r] : 0.0);
                 } else {
-                    if (al) cf += (dla_l[r] * dta_l[r] - mu_t) / t_l[r];
-                    if (au) cf -= (dla_u[r] * dta_u[r] - mu_t) / t_u[r];
+                    if (al) c += (dla_l[r] * dta_l[r] - mu_t) / t_l[r];
+                    if (au) c -= (dla_u[r] * dta_u[r] - mu_t) / t_u[r];
                 }
-                bufA[s_kc[r]] = cf;
+                cf[s_kc[r]] = c;
             }
             WSYNC();
             for (int e = lane; e < NS * 10; e += 64) {
                 const int k = e / 10, j = e % 10;
-                double acc = gt[e] + bufA[k * 12 + j];
+                double acc = gt[e] + cf[k * 12 + j];
                 if (k < N) {
-                    acc = fma(a.CD[(k * 2 + 0) * 10 + j], bufA[k * 12 + 10], acc);
-                    acc = fma(a.CD[(k * 2 + 1) * 10 + j], bufA[k * 12 + 11], acc);
+                    acc = fma(a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
+                    acc = fma(a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
                 }
                 gt[e] = acc;        // pass 1 adds its increment on top of the predictor's gradient
             }
             WSYNC();
 
-            // ---- backward Riccati sweep ----
+            // ---- factorisation (pass 0 only): P_k, K_k, Guu^-1, P_{k+1} rb_k ----
             if (pass == 0) {
                 {   // terminal stage
                     const int i = lane >> 3, j = lane & 7;
                     double v = a.Hs[(N * 10 + i) * 10 + j];
                     if (i == j) v += gam[N * 12 + i];
                     Pn[lane] = v;
-                    if (i <= j) Pl[N * 36 + sym8(i, j)] = v;
-                    if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
+                    Pg[(size_t)N * 64 + lane] = v;
                 }
                 // this lane's entry of the stage Hessian / general rows, prefetched one stage ahead
                 int gi = 0, gj = 0;
@@ -369,39 +392,32 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 double regH = a.Hs[((N - 1) * 10 + gi) * 10 + gj];
                 double rc0i = a.CD[((N - 1) * 2 + 0) * 10 + gi], rc0j = a.CD[((N - 1) * 2 + 0) * 10 + gj];
                 double rc1i = a.CD[((N - 1) * 2 + 1) * 10 + gi], rc1j = a.CD[((N - 1) * 2 + 1) * 10 + gj];
-                WSYNC();
-                for (int k = N - 1; k >= 0; k--) {
-                    const double *AB = ABl + k * LIN_REC;
+                // second product of the W phase: lanes 0..15 -> B part of W, lanes 16..23 -> P_{k+1} rb_k
+                const int i2 = (lane < 16) ? (lane >> 1) : ((lane < 24) ? lane - 16 : 0);
+                stream_sweep<-1>(linb, stage2, N, lane, [&](int k, const double *AB) {
                     const double Hk = regH, c0i = rc0i, c0j = rc0j, c1i = rc1i, c1j = rc1j;
                     if (k > 0) {
                         regH = a.Hs[((k - 1) * 10 + gi) * 10 + gj];
                         rc0i = a.CD[((k - 1) * 2 + 0) * 10 + gi]; rc0j = a.CD[((k - 1) * 2 + 0) * 10 + gj];
                         rc1i = a.CD[((k - 1) * 2 + 1) * 10 + gi]; rc1j = a.CD[((k - 1) * 2 + 1) * 10 + gj];
                     }
-                    // W = P_{k+1} [A B]  (64 + 16 entries) ; h = P_{k+1} rb_k + p_{k+1}
+                    // W = P_{k+1} [A B]  (64 + 16 entries) and P_{k+1} rb_k (8 entries): two products per lane
                     {
                         const int i = lane >> 3, j = lane & 7;
-                        double acc = 0.0;
+                        const double *q = (lane < 16) ? AB + 64 + (lane & 1) : rb + k * 8;
+                        const int qs = (lane < 16) ? 2 : 1;
+                        double acc = 0.0, acc2 = 0.0;
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(Pn[i * 8 + l], AB[l * 8 + j], acc);
-                        Ws[i * 10 + j] = acc;
-                        if (lane < 16) {
-                            const int i2 = lane >> 1, j2 = lane & 1;
-                            double acc2 = 0.0;
-#pragma unroll
-                            for (int l = 0; l < 8; l++) acc2 = fma(Pn[i2 * 8 + l], AB[64 + l * 2 + j2], acc2);
-                            Ws[i2 * 10 + 8 + j2] = acc2;
-                        } else if (lane < 24) {
-                            const int i2 = lane - 16;
-                            double acc2 = 0.0;
-#pragma unroll
-                            for (int l = 0; l < 8; l++) acc2 = fma(Pn[i2 * 8 + l], rb[k * 8 + l], acc2);
-                            Prb[k * 8 + i2] = acc2;
-                            hs[i2] = acc2 + pv[(k + 1) * 8 + i2];
+                        for (int l = 0; l < 8; l++) {
+                            acc = fma(Pn[i * 8 + l], AB[l * 8 + j], acc);
+                            acc2 = fma(Pn[i2 * 8 + l], q[l * qs], acc2);
                         }
+                        Ws[i * 10 + j] = acc;
+                        if (lane < 16) Ws[i2 * 10 + 8 + (lane & 1)] = acc2;
+                        else if (lane < 24) Prb[k * 8 + i2] = acc2;
                     }
                     WSYNC();
-                    // G = Ht + [A B]' W  (upper triangle, 55 entries) ; gz = gt_k + [A B]' h
+                    // G = H~ + [A B]' W  (upper triangle, 55 entries)
                     if (lane < 55) {
                         double acc = Hk;
                         if (gi == gj) acc += gam[k * 12 + gi];
@@ -412,15 +428,8 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                         Gs[gi * 10 + gj] = acc;
                         Gs[gj * 10 + gi] = acc;
                     }
-                    if (lane < 10) {
-                        const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
-                        double acc = gt[k * 10 + lane];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], hs[l], acc);
-                        gz[lane] = acc;
-                    }
                     WSYNC();
-                    // P_k = Gxx - Gux' Guu^-1 Gux ; gains ; p_k
+                    // P_k = Gxx - Gux' Guu^-1 Gux ; K_k = Guu^-1 Gux
                     {
                         const double g00 = Gs[88], g01 = Gs[89], g11 = Gs[99];
                         const double idet = 1.0 / (g00 * g11 - g01 * g01);
@@ -430,108 +439,93 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                         const double ai = Gs[i * 10 + 8], bi = Gs[i * 10 + 9], cj = Gs[j * 10 + 8], dj = Gs[j * 10 + 9];
                         const double v = Gs[i * 10 + j] - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
                         Pn[lane] = v;
-                        if (i0 <= j0) Pl[k * 36 + sym8(i0, j0)] = v;
-                        if (lane < 16) Gux[k * 16 + lane] = Gs[(lane & 7) * 10 + 8 + (lane >> 3)];
+                        Pg[(size_t)k * 64 + lane] = v;
+                        if (lane < 16) {      // K[a][jj], a = lane >> 3
+                            const int jj = lane & 7;
+                            const double gx0 = Gs[jj * 10 + 8], gx1 = Gs[jj * 10 + 9];
+                            Kl[k * 16 + lane] = (lane < 8) ? (Gi0 * gx0 + Gi1 * gx1) : (Gi1 * gx0 + Gi2 * gx1);
+                        }
                         if (lane == 0) { Ginv[k * 4 + 0] = Gi0; Ginv[k * 4 + 1] = Gi1; Ginv[k * 4 + 2] = Gi2; }
-                        const double kf0 = Gi0 * gz[8] + Gi1 * gz[9], kf1 = Gi1 * gz[8] + Gi2 * gz[9];
-                        if (lane < 2) kff[k * 2 + lane] = lane ? kf1 : kf0;
-                        if (lane < 8) pv[k * 8 + lane] = gz[lane] - (Gs[lane * 10 + 8] * kf0 + Gs[lane * 10 + 9] * kf1);
                     }
                     WSYNC();
-                }
-            } else {
-                // vector-only sweep with the stored factorisation
-                if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
-                const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
-                WSYNC();
-                for (int k = N - 1; k >= 0; k--) {
-                    const double *AB = ABl + k * LIN_REC;
-                    if (lane < 10) {
-                        double acc = gt[k * 10 + lane];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], Prb[k * 8 + l] + pv[(k + 1) * 8 + l], acc);
-                        gz[lane] = acc;
-                    }
-                    WSYNC();
-                    {
-                        const double Gi0 = Ginv[k * 4 + 0], Gi1 = Ginv[k * 4 + 1], Gi2 = Ginv[k * 4 + 2];
-                        const double kf0 = Gi0 * gz[8] + Gi1 * gz[9], kf1 = Gi1 * gz[8] + Gi2 * gz[9];
-                        if (lane < 2) kff[k * 2 + lane] = lane ? kf1 : kf0;
-                        if (lane < 8) pv[k * 8 + lane] = gz[lane] - (Gux[k * 16 + lane] * kf0 + Gux[k * 16 + 8 + lane] * kf1);
-                    }
-                    WSYNC();
-                }
+                });
             }
 
-            // ---- forward sweep: dz (into bufA), dpi (into pv, corrector pass or no inequalities) ----
-            const bool want_dpi = (pass == 1) || (a.m_act == 0);
-            if (lane < 8) dxs[lane] = 0.0;
-            WSYNC();
-            for (int k = 0; k < N; k++) {
-                const double *AB = ABl + k * LIN_REC;
-                const double *dxc = dxs + (k & 1) * 8;
-                if (lane < 2) {
-                    double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { t0 = fma(Gux[k * 16 + j], dxc[j], t0); t1 = fma(Gux[k * 16 + 8 + j], dxc[j], t1); }
-                    const double Gi0 = Ginv[k * 4 + 0], Gi1 = Ginv[k * 4 + 1], Gi2 = Ginv[k * 4 + 2];
-                    const double du = lane ? (-(Gi1 * t0 + Gi2 * t1) - kff[k * 2 + 1]) : (-(Gi0 * t0 + Gi1 * t1) - kff[k * 2 + 0]);
-                    dus[lane] = du;
-                    dz[k * 10 + 8 + lane] = du;
-                } else if (lane >= 8 && lane < 16) {
-                    if (want_dpi) {
-                        const int i = lane - 8;
-                        double acc = pv[k * 8 + i];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(Pl[k * 36 + sym8(i, l)], dxc[l], acc);
-                        pv[k * 8 + i] = acc;        // dpi_k
-                    }
-                } else if (lane >= 16 && lane < 24) {
-                    dz[k * 10 + lane - 16] = dxc[lane - 16];
-                }
-                WSYNC();
-                if (lane < 8) {
-                    double dxn = rb[k * 8 + lane];
-#pragma unroll
-                    for (int l = 0; l < 8; l++) dxn = fma(AB[lane * 8 + l], dxc[l], dxn);
-                    dxn = fma(AB[64 + lane * 2 + 0], dus[0], dxn);
-                    dxn = fma(AB[64 + lane * 2 + 1], dus[1], dxn);
-                    dxs[((k + 1) & 1) * 8 + lane] = dxn;
-                }
-                WSYNC();
-            }
+            // ---- vector recursion: p_k = gt_x - K'gt_u + (A - B K)'(P_{k+1} rb_k + p_{k+1}) ----
+            if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
             {
-                const double *dxc = dxs + (N & 1) * 8;
-                if (lane < 8) { dz[N * 10 + lane] = dxc[lane]; }
-                else if (lane < 10) { dz[N * 10 + lane] = 0.0; }
-                else if (lane >= 16 && lane < 24 && want_dpi) {
-                    const int i = lane - 16;
-                    double acc = pv[N * 8 + i];
+                const int j = lane & 7;
+                stream_sweep<-1>(linb, stage2, N, lane, [&](int k, const double *AB) {
+                    const double k0 = Kl[k * 16 + j], k1 = Kl[k * 16 + 8 + j];
+                    double acc = gt[k * 10 + j] - k0 * gt[k * 10 + 8] - k1 * gt[k * 10 + 9];
 #pragma unroll
-                    for (int l = 0; l < 8; l++) acc = fma(Pl[N * 36 + sym8(i, l)], dxc[l], acc);
-                    pv[N * 8 + i] = acc;
+                    for (int l = 0; l < 8; l++) {
+                        const double h = Prb[k * 8 + l] + pv[(k + 1) * 8 + l];
+                        acc = fma(AB[l * 8 + j] - k0 * AB[64 + l * 2] - k1 * AB[64 + l * 2 + 1], h, acc);
+                    }
+                    if (lane < 8) pv[k * 8 + j] = acc;
+                    WSYNC();
+                });
+            }
+            // feed-forward terms of all stages in parallel: kff_k = Guu^-1 (gt_u + B'(P_{k+1} rb_k + p_{k+1}))
+            for (int k = lane; k < N; k += 64) {
+                const double *rec = linb + (size_t)k * LIN_REC;
+                double g0 = gt[k * 10 + 8], g1 = gt[k * 10 + 9];
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const double h = Prb[k * 8 + l] + pv[(k + 1) * 8 + l];
+                    g0 = fma(rec[64 + l * 2 + 0], h, g0);
+                    g1 = fma(rec[64 + l * 2 + 1], h, g1);
+                }
+                kff[k * 2 + 0] = Ginv[k * 4 + 0] * g0 + Ginv[k * 4 + 1] * g1;
+                kff[k * 2 + 1] = Ginv[k * 4 + 1] * g0 + Ginv[k * 4 + 2] * g1;
+            }
+            if (lane < 8) dz[lane] = 0.0;
+            WSYNC();
+
+            // ---- forward recursion: dx_{k+1} = rb_k - B kff_k + (A - B K) dx_k ----
+            {
+                const int i = lane & 7;
+                stream_sweep<+1>(linb, stage2, N, lane, [&](int k, const double *AB) {
+                    const double b0 = AB[64 + i * 2], b1 = AB[64 + i * 2 + 1];
+                    double acc = rb[k * 8 + i] - b0 * kff[k * 2] - b1 * kff[k * 2 + 1];
+#pragma unroll
+                    for (int l = 0; l < 8; l++)
+                        acc = fma(AB[i * 8 + l] - b0 * Kl[k * 16 + l] - b1 * Kl[k * 16 + 8 + l], dz[k * 10 + l], acc);
+                    if (lane < 8) dz[(k + 1) * 10 + i] = acc;
+                    WSYNC();
+                });
+            }
+            // inputs and costate steps of all stages in parallel
+            const bool want_dpi = (pass == 1) || (a.m_act == 0);
+            for (int e = lane; e < NS * 2; e += 64) {
+                const int k = e >> 1, aa = e & 1;
+                double acc = 0.0;
+                if (k < N) {
+                    acc = -kff[k * 2 + aa];
+#pragma unroll
+                    for (int l = 0; l < 8; l++) acc = fma(-Kl[k * 16 + aa * 8 + l], dz[k * 10 + l], acc);
+                }
+                dz[k * 10 + 8 + aa] = acc;
+            }
+            if (want_dpi) {
+                for (int e = lane; e < NS * 8; e += 64) {
+                    const int k = e >> 3, i = e & 7;
+                    double acc = pv[e];
+#pragma unroll
+                    for (int l = 0; l < 8; l++) acc = fma(Pg[(size_t)k * 64 + i * 8 + l], dz[k * 10 + l], acc);
+                    pv[e] = acc;        // dpi_k = P_k dx_k + p_k
                 }
             }
             WSYNC();
 
-            // ---- R dz, slack / multiplier steps, step length ----
-            for (int e = lane; e < NS * 12; e += 64) {
-                const int k = e / 12, c = e % 12;
-                double v = 0.0;
-                if (c < 10) v = dz[k * 10 + c];
-                else if (k < N) {
-#pragma unroll
-                    for (int j = 0; j < 10; j++) v = fma(a.CD[(k * 2 + c - 10) * 10 + j], dz[k * 10 + j], v);
-                }
-                Rz[e] = v;
-            }
-            WSYNC();
+            // ---- slack / multiplier steps, step length ----
             double amax = 1.0, mu_aff = 0.0;
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
                 dlam_l[r] = dlam_u[r] = dt_l[r] = dt_u[r] = 0.0;
                 if (s_kc[r] < 0) continue;
-                const double drz = Rz[s_kc[r]];
+                const double drz = row_dot(s_kc[r], dz);
                 if (fin(s_dl[r])) {
                     const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + dla_l[r] * dta_l[r] - mu_t;
                     dt_l[r] = drz + rd_l[r];
@@ -597,7 +591,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         }
         for (int e = lane; e < NS * 8; e += 64) pib[e] = (e < 8) ? 0.0 : pi[e];
         for (int e = lane; e < NS * 24; e += 64) lamb[e] = 0.0;
-        WSYNC();
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
@@ -606,7 +600,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             lamb[k * 24 + 12 + c] = lam_u[r];
         }
     }
-    WSYNC();
+    __syncthreads();
     if (lane < 2) a.u0[(size_t)b * 2 + lane] = uw[lane];
     if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; }
 }
@@ -621,9 +615,9 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g;
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P;
     const int N = h->N, NS = h->NS;
-    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 12 + 36) + (size_t)N * (8 + 2 + 16 + 4 + 8 + LIN_REC) + 64 + 80 + 80 + 100 + 8 + 12 + 16 + 4);
+    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 10) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
     if (lds > 160 * 1024) return 1;
     const int per_lane = (h->nslots + 63) / 64;
     if (per_lane <= 5) {
