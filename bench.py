@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N>1 path on one GPU")
+    ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,14 +123,19 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from ihm2_amd.solver import BatchedOcpSolver
 
     B = args.batch
     ocp, track = build_problem(B)
-    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, device=local_rank)
+    device = local_rank if args.device is None else args.device
+    on_gpu = args.dist_backend == "nccl"
+    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, device=device)
     x0 = sample_x0(track, B, seed=20240607 + rank)
     solver.set_x0(x0)
     solver.init_guess()
@@ -143,9 +151,11 @@ def main():
         if dist is not None:
             import torch
 
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -168,19 +178,26 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        from ihm2_amd.dist import all_gather_blocks
+
+        dev = "cuda" if on_gpu else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # final gather of the results over RCCL/xGMI: u0 (B,2) and status of every rank, device to device
         tg0 = time.perf_counter()
-        u0_dev = torch.empty((B, 2), dtype=torch.float64, device="cuda")
-        st_dev = torch.empty((B,), dtype=torch.int32, device="cuda")
-        solver.get_u0_device(u0_dev.data_ptr()); solver.get_status_device(st_dev.data_ptr()); solver.synchronize()
-        u0_all = [torch.empty_like(u0_dev) for _ in range(world)]
-        st_all = [torch.empty_like(st_dev) for _ in range(world)]
-        dist.all_gather(u0_all, u0_dev); dist.all_gather(st_all, st_dev)
-        torch.cuda.synchronize()
+        if on_gpu:
+            u0_dev = torch.empty((B, 2), dtype=torch.float64, device="cuda")
+            st_dev = torch.empty((B,), dtype=torch.int32, device="cuda")
+            solver.get_u0_device(u0_dev.data_ptr()); solver.get_status_device(st_dev.data_ptr()); solver.synchronize()
+        else:
+            u0_dev = torch.from_numpy(solver.get_u0()); st_dev = torch.from_numpy(status.copy())
+        u0_all = all_gather_blocks(u0_dev, B * world)
+        st_all = [all_gather_blocks(st_dev, B * world)]
+        if on_gpu:
+            torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg0) * 1e3
+        assert u0_all.shape == (B * world, 2)
         status_all = torch.cat(st_all).cpu().numpy()
     else:
         gather_ms = 0.0
@@ -198,6 +215,17 @@ def main():
             kname, kms, kflops = "k_qp_wave", ms_qp, f_qp * B
         achieved = kflops / (kms * 1e-3) / 1e12
         alg_bytes = 8 * (2 * (N_H + 1) * 8 + 2 * N_H * 2 + 8 + 5)          # 6632 B per solve
+        # HBM traffic per launch of the dominant kernel: PMC counters (FETCH_SIZE, WRITE_SIZE) cannot be read from
+        # inside this process; they come from the committed rocprofv3 --pmc passes of this same command
+        traffic, traffic_src = None, None
+        try:
+            prof = os.path.join(ROOT, "profiles", "r1", "current_summary.json")
+            kk = json.load(open(prof))["kernels"]
+            key = [n for n in kk if n.startswith(kname.split("<")[0])][0]
+            if B == 1024:
+                traffic, traffic_src = kk[key]["hbm_traffic_bytes_per_launch"], "profiles/r1/current_summary.json"
+        except Exception:
+            pass
         out = {
             "metric": "NMPC RTI solves/s (batch), N=40, nx=8 (6-DOF bicycle), fkin6",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,7 +235,8 @@ def main():
                                    f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 readback",
                        "batch_per_gpu": B, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards"},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes * B,
                          "note": "fp64 VALU/latency-bound path (no MFMA on it): peak = MI355X fp64 vector = fp64 matrix "
                                  "peak; achieved = algorithmic flops (SURVEY.md 8d model) / HIP-event kernel time",
                          "kernel_ms": kms, "linearize_ms": ms_lin, "qp_ms": ms_qp, "n_ipm_mean": n_ipm, "M": M_SUB,
