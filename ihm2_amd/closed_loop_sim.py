@@ -1,0 +1,143 @@
+"""Model-in-the-loop closed loop, batched on the GPU (BASELINE.json config 5).
+
+Semantics of the reference's MiL loop ``main()`` (``python/main.py:438-517``): start at ``s = -6``, every
+control step call the controller, advance the plant in Frenet coordinates with the same track table,
+abort an instance on NaN, stop it one metre after a full lap, report lap time / mean speed / controller
+run time (``:561-575``).  Plant variants ``SimModelVariant`` (``python/main.py:337-341``,
+``new_python/closed_loop_sim.py:27-31``): KIN6, DYN6, KIN6_DYN6 (speed switch ``v^2 sin(beta)/l_R <= 3``,
+``python/main.py:482-489``).  The reference integrates the plant with IRK Radau-IIA, 4 stages x 100 steps
+(``python/main.py:395-400``); here the plant is RK4 with ``M_sim`` sub-steps (default 100).
+
+Names kept from the refactor skeleton: ``SimulatorConfig`` (sic ``colloaction_type``), ``Simulator``,
+``MultiModelSimulator`` (``new_python/simulator.py:25-62``), ``closed_loop`` with its argument list
+(``new_python/closed_loop_sim.py:34-42``).
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from enum import Enum, auto
+from typing import Callable
+
+import numpy as np
+
+from .controller import IHM2Controller
+from .track import MotionPlan, track_table
+
+
+class SimModelVariant(Enum):
+    KIN6 = auto()
+    DYN6 = auto()
+    KIN6_DYN6 = auto()
+    DYN10 = auto()          # not implemented
+
+
+_PLANT_CODE = {SimModelVariant.KIN6: 0, SimModelVariant.DYN6: 1, SimModelVariant.KIN6_DYN6: -1}
+
+
+@dataclass
+class SimulatorConfig:
+    sampling_time: float
+    integrator_type: str = "ERK"
+    colloaction_type: str = "GAUSS_RADAU_IIA"      # accepted for drop-in; the device plant is RK4 x num_steps
+    num_steps: int = 100
+
+
+class Simulator:
+    """Batched plant on the device that already holds the controller's state (``new_python/simulator.py:42-47``)."""
+
+    def __init__(self, controller: IHM2Controller, config: SimulatorConfig, variant: SimModelVariant = SimModelVariant.KIN6_DYN6):
+        if variant not in _PLANT_CODE:
+            raise NotImplementedError(f"plant variant {variant.name}")
+        self.controller, self.config, self.variant = controller, config, variant
+
+    def simulate(self, x: np.ndarray, u: np.ndarray) -> np.ndarray:
+        """Host arrays in, host arrays out: ``x`` (B,8), ``u`` (B,2) -> next state (B,8)."""
+        return self.controller.solver.sim_step(x, u, model=_PLANT_CODE[self.variant], M_sim=self.config.num_steps)
+
+    def advance(self) -> None:
+        """x0 <- plant(x0, u0 of the last solve) without leaving the device."""
+        self.controller.solver.sim_advance(model=_PLANT_CODE[self.variant], M_sim=self.config.num_steps)
+
+
+class MultiModelSimulator(Simulator):
+    """``new_python/simulator.py:54-62``: the kinematic/dynamic switch is evaluated per instance on the device."""
+
+    def __init__(self, controller: IHM2Controller, config: SimulatorConfig, condition: Callable | None = None):
+        super().__init__(controller, config, SimModelVariant.KIN6_DYN6)
+        self.condition = condition
+
+
+@dataclass
+class ClosedLoopResult:
+    x: np.ndarray            # (steps+1, B, 8)
+    u: np.ndarray            # (steps, B, 2)
+    status: np.ndarray       # (steps, B)
+    alive: np.ndarray        # (B,) still running at the end
+    finished: np.ndarray     # (B,) completed a lap
+    lap_time: np.ndarray     # (B,) seconds (nan if not finished)
+    runtimes_ms: list = field(default_factory=list)
+    alive_history: np.ndarray | None = None   # (steps, B) alive at the start of each step
+
+    def stats(self) -> dict:
+        v = np.hypot(self.x[..., 3], self.x[..., 4])
+        return {"laps_finished": int(self.finished.sum()), "failed": int((~self.alive & ~self.finished).sum()),
+                "mean_speed": float(np.nanmean(v)), "mean_runtime_ms": float(np.mean(self.runtimes_ms)),
+                "max_runtime_ms": float(np.max(self.runtimes_ms)),
+                "control_steps_per_s": float(self.u.shape[0] * self.u.shape[1] / (np.sum(self.runtimes_ms) * 1e-3))}
+
+
+def run_closed_loop(controller: IHM2Controller, simulator: Simulator, x0: np.ndarray, n_steps: int, lap_length: float | None = None,
+                    interation_end_callback: Callable | None = None) -> ClosedLoopResult:
+    """``python/main.py:448-517`` for a batch.  Instances that fail (status not in {0,2}, NaN) or finish the lap are
+    frozen: they keep their last state and a zero input, as the reference stops its single loop."""
+    B = controller.B
+    x = np.asarray(x0, dtype=np.float64).reshape(B, 8).copy()
+    xs, us, sts, runtimes = [x.copy()], [], [], []
+    alive = np.ones(B, dtype=bool)
+    finished = np.zeros(B, dtype=bool)
+    lap_time = np.full(B, np.nan)
+    alive_hist = []
+    for i in range(n_steps):
+        alive_hist.append(alive.copy())
+        t0 = time.perf_counter()
+        u = controller.compute_control(x)
+        runtimes.append((time.perf_counter() - t0) * 1e3)
+        st = controller.last_status.copy()
+        bad = alive & ~np.isin(st, (0, 2))
+        alive &= ~bad
+        u = np.where(alive[:, None], np.nan_to_num(u), 0.0)
+        xn = simulator.simulate(x, u)
+        nan = alive & np.any(np.isnan(xn), axis=1)          # python/main.py:503-504
+        alive &= ~nan
+        x = np.where(alive[:, None], xn, x)
+        if lap_length is not None:
+            done = alive & (x[:, 0] > lap_length + 1.0)     # python/main.py:514-517
+            lap_time[done] = (i + 1) * controller.dt
+            finished |= done
+            alive &= ~done
+        xs.append(x.copy()); us.append(u); sts.append(st)
+        if interation_end_callback is not None:
+            interation_end_callback(i, x, u, st)
+        if not alive.any():
+            break
+    return ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
+
+
+def closed_loop(track_data: str | MotionPlan, simulator_type=SimModelVariant.KIN6_DYN6, motion_planner_type: type | None = None,
+                motion_tracker_type: type = IHM2Controller, low_level_controller_type: type | None = None,
+                interation_end_callback: Callable | None = None, cleanup_callback: Callable | None = None, *,
+                batch_size: int = 1, n_steps: int = 501, x0: np.ndarray | None = None, **controller_kwargs) -> ClosedLoopResult:
+    """Argument list of ``new_python/closed_loop_sim.py:34-42`` (a pseudo-code skeleton there).  ``track_data`` is a
+    track name or a tripled motion plan; the motion tracker is the NMPC controller; there is no separate motion
+    planner / low-level controller in the reference's loop (``python/main.py:448-517``)."""
+    plan = track_table(track_data) if isinstance(track_data, str) else track_data
+    controller = motion_tracker_type(plan.s_ref, plan.kappa_ref, batch_size=batch_size, **controller_kwargs)
+    sim = Simulator(controller, SimulatorConfig(sampling_time=controller.dt), simulator_type)
+    if x0 is None:
+        x0 = np.zeros((batch_size, 8))
+        x0[:, 0] = -6.0                                     # python/main.py:438-441
+    res = run_closed_loop(controller, sim, x0, n_steps, plan.lap_length, interation_end_callback)
+    if cleanup_callback is not None:
+        cleanup_callback(res)
+    return res
