@@ -41,7 +41,7 @@ struct QpArgs {
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g, *P;
+    double *g, *P, *M, *Mt;
 };
 
 #define INF_BOUND 1e20
@@ -85,6 +85,51 @@ __device__ __forceinline__ double wave_nanmax(double v)
     return v;
 }
 
+// Sum over aligned groups of 8 consecutive lanes with DPP moves (VALU speed, no LDS crossbar):
+// quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror.  Every lane of the group gets the total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum8(double v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+
+// Ring of D coalesced 512-byte loads running D-1 stages ahead of a sequential sweep over a (N,64) array.
+// DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  body(k, value of element `lane` of row k).
+template <int DIR, int D, typename F>
+__device__ __forceinline__ void stream_rows(const double *rows, int N, int lane, F &&body)
+{
+    double r[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const int kk = (DIR < 0) ? N - 1 - d : d;
+        r[d] = (d < N) ? rows[(size_t)kk * 64 + lane] : 0.0;
+    }
+    for (int s0 = 0; s0 < N; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int s = s0 + d;
+            if (s >= N) break;
+            const int k = (DIR < 0) ? N - 1 - s : s;
+            const double v = r[d];
+            if (s + D < N) {
+                const int kk = (DIR < 0) ? N - 1 - (s + D) : s + D;
+                r[d] = rows[(size_t)kk * 64 + lane];
+            }
+            body(k, v);
+        }
+    }
+}
+
 // upper-triangle enumeration of a 10x10 symmetric matrix: entry e in [0,55) -> (i <= j)
 __device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
 {
@@ -96,16 +141,16 @@ __device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
 }
 
 // Sequential sweep over the stages with the linearisation records streamed from HBM/L2.
-// DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  A register ring holds the next four records (lane e
+// DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  A register ring holds the next D records (lane e
 // keeps elements e and 64+e of each); the record of the next stage is written to the other LDS slot at
-// the top of a stage, so the loads are consumed >= 3 stages after they were issued.
+// the top of a stage, so a load is consumed D-1 stages after it was issued.
 // body(k, rec) must end with WSYNC().
-template <int DIR, typename F>
+template <int DIR, int D, typename F>
 __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2, int N, int lane, F &&body)
 {
-    double ra[4], rb2[4];
+    double ra[D], rb2[D];
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
+    for (int d = 0; d < D; d++) {
         const int kk = (DIR < 0) ? N - 1 - d : d;
         const bool ok = d < N;
         ra[d] = ok ? linb[(size_t)kk * LIN_REC + lane] : 0.0;
@@ -114,19 +159,19 @@ __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2,
     stage2[lane] = ra[0];
     if (lane < 24) stage2[64 + lane] = rb2[0];
     WSYNC();
-    for (int s0 = 0; s0 < N; s0 += 4) {
+    for (int s0 = 0; s0 < N; s0 += D) {
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
+        for (int d = 0; d < D; d++) {
             const int s = s0 + d;
             if (s >= N) break;
             const int k = (DIR < 0) ? N - 1 - s : s;
             double *cur = stage2 + (s & 1) * LIN_REC, *nxt = stage2 + ((s + 1) & 1) * LIN_REC;
             if (s + 1 < N) {
-                nxt[lane] = ra[(d + 1) & 3];
-                if (lane < 24) nxt[64 + lane] = rb2[(d + 1) & 3];
+                nxt[lane] = ra[(d + 1) % D];
+                if (lane < 24) nxt[64 + lane] = rb2[(d + 1) % D];
             }
-            if (s + 4 < N) {
-                const int kk = (DIR < 0) ? N - 1 - (s + 4) : s + 4;
+            if (s + D < N) {
+                const int kk = (DIR < 0) ? N - 1 - (s + D) : s + D;
                 ra[d] = linb[(size_t)kk * LIN_REC + lane];
                 if (lane < 24) rb2[d] = linb[(size_t)kk * LIN_REC + 64 + lane];
             }
@@ -166,6 +211,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
     double *gb = a.g + (size_t)b * NS * 10;
     double *Pg = a.P + (size_t)b * NS * 64;
+    double *Mg = a.M + (size_t)b * N * 64, *Mtg = a.Mt + (size_t)b * N * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 24;
 
@@ -306,36 +352,49 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         }
         WSYNC();
         // ---- stationarity and dynamics residuals ----
-        res_g = 0.0; res_b = 0.0;
+        // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
         for (int e = lane; e < NS * 10; e += 64) {
             const int k = e / 10, j = e % 10;
             double acc = gb[e];
 #pragma unroll
             for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
             if (k < N) {
-                const double *rec = linb + (size_t)k * LIN_REC;
-#pragma unroll
-                for (int l = 0; l < 8; l++) acc = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pi[(k + 1) * 8 + l], acc);
                 acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
                 acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
             }
             if (j < 8) acc -= pi[k * 8 + j];
             acc -= cf[k * 12 + j];
-            if ((k == 0 && j < 8) || (k == N && j >= 8)) acc = 0.0;
             gt[e] = acc;
-            res_g = nanmax(res_g, fabs(acc));
         }
-        for (int e = lane; e < N * 8; e += 64) {
-            const int k = e / 8, i = e % 8;
-            const double *rec = linb + (size_t)k * LIN_REC;
-            double acc = rec[80 + i] - z[(k + 1) * 10 + i];
+        // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
+        // between stages: the loop runs at the pace of the LDS staging)
+        stream_sweep<+1, 8>(linb, stage2, N, lane, [&](int k, const double *AB) {
+            if (lane < 10) {
+                const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
+                double acc = gt[k * 10 + lane];
 #pragma unroll
-            for (int l = 0; l < 8; l++) acc = fma(rec[i * 8 + l], z[k * 10 + l], acc);
-            acc = fma(rec[64 + i * 2 + 0], z[k * 10 + 8], acc);
-            acc = fma(rec[64 + i * 2 + 1], z[k * 10 + 9], acc);
-            rb[e] = acc;
-            res_b = nanmax(res_b, fabs(acc));
+                for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], pi[(k + 1) * 8 + l], acc);
+                gt[k * 10 + lane] = acc;
+            } else if (lane >= 16 && lane < 24) {
+                const int i = lane - 16;
+                double acc = AB[80 + i] - z[(k + 1) * 10 + i];
+#pragma unroll
+                for (int l = 0; l < 8; l++) acc = fma(AB[i * 8 + l], z[k * 10 + l], acc);
+                acc = fma(AB[64 + i * 2 + 0], z[k * 10 + 8], acc);
+                acc = fma(AB[64 + i * 2 + 1], z[k * 10 + 9], acc);
+                rb[k * 8 + i] = acc;
+            }
+            WSYNC();
+        });
+        // (iii) masks and norms
+        res_g = 0.0; res_b = 0.0;
+        for (int e = lane; e < NS * 10; e += 64) {
+            const int k = e / 10, j = e % 10;
+            double v = gt[e];
+            if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
+            res_g = nanmax(res_g, fabs(v));
         }
+        for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e]));
         res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m);
         mu = wave_sum(mu_acc) * inv_m;
         if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; }
@@ -394,7 +453,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 double rc1i = a.CD[((N - 1) * 2 + 1) * 10 + gi], rc1j = a.CD[((N - 1) * 2 + 1) * 10 + gj];
                 // second product of the W phase: lanes 0..15 -> B part of W, lanes 16..23 -> P_{k+1} rb_k
                 const int i2 = (lane < 16) ? (lane >> 1) : ((lane < 24) ? lane - 16 : 0);
-                stream_sweep<-1>(linb, stage2, N, lane, [&](int k, const double *AB) {
+                stream_sweep<-1, 4>(linb, stage2, N, lane, [&](int k, const double *AB) {
                     const double Hk = regH, c0i = rc0i, c0j = rc0j, c1i = rc1i, c1j = rc1j;
                     if (k > 0) {
                         regH = a.Hs[((k - 1) * 10 + gi) * 10 + gj];
@@ -448,51 +507,64 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                         if (lane == 0) { Ginv[k * 4 + 0] = Gi0; Ginv[k * 4 + 1] = Gi1; Ginv[k * 4 + 2] = Gi2; }
                     }
                     WSYNC();
+                    // closed-loop matrix M_k = A - B K in both lane layouts (row-major for the forward
+                    // recursion, transposed for the vector recursion), streamed back by those sweeps
+                    {
+                        const int hi = lane >> 3, lo = lane & 7;
+                        Mg[(size_t)k * 64 + lane] = AB[hi * 8 + lo] - AB[64 + hi * 2] * Kl[k * 16 + lo] - AB[64 + hi * 2 + 1] * Kl[k * 16 + 8 + lo];
+                        Mtg[(size_t)k * 64 + lane] = AB[lo * 8 + hi] - AB[64 + lo * 2] * Kl[k * 16 + hi] - AB[64 + lo * 2 + 1] * Kl[k * 16 + 8 + hi];
+                    }
                 });
             }
 
-            // ---- vector recursion: p_k = gt_x - K'gt_u + (A - B K)'(P_{k+1} rb_k + p_{k+1}) ----
-            if (lane < 8) pv[N * 8 + lane] = gt[N * 10 + lane];
+            // ---- vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) ----
+            // the part without p_{k+1} for all stages in parallel ...
+            for (int e = lane; e < NS * 8; e += 64) {
+                const int k = e >> 3, j = e & 7;
+                double v = gt[k * 10 + j];
+                if (k < N) v -= Kl[k * 16 + j] * gt[k * 10 + 8] + Kl[k * 16 + 8 + j] * gt[k * 10 + 9];
+                pv[e] = v;
+            }
+            WSYNC();
+            // ... then one multiply + an 8-lane DPP sum per stage: lane (j, l) holds M_k[l][j]
             {
-                const int j = lane & 7;
-                stream_sweep<-1>(linb, stage2, N, lane, [&](int k, const double *AB) {
-                    const double k0 = Kl[k * 16 + j], k1 = Kl[k * 16 + 8 + j];
-                    double acc = gt[k * 10 + j] - k0 * gt[k * 10 + 8] - k1 * gt[k * 10 + 9];
-#pragma unroll
-                    for (int l = 0; l < 8; l++) {
-                        const double h = Prb[k * 8 + l] + pv[(k + 1) * 8 + l];
-                        acc = fma(AB[l * 8 + j] - k0 * AB[64 + l * 2] - k1 * AB[64 + l * 2 + 1], h, acc);
-                    }
-                    if (lane < 8) pv[k * 8 + j] = acc;
+                const int j = lane >> 3, l = lane & 7;
+                stream_rows<-1, 8>(Mtg, N, lane, [&](int k, double m) {
+                    const double t = sum8(m * (Prb[k * 8 + l] + pv[(k + 1) * 8 + l]));
+                    if (l == 0) pv[k * 8 + j] += t;
                     WSYNC();
                 });
             }
-            // feed-forward terms of all stages in parallel: kff_k = Guu^-1 (gt_u + B'(P_{k+1} rb_k + p_{k+1}))
+            // feed-forward terms kff_k = Guu^-1 (gt_u + B'(P_{k+1} rb_k + p_{k+1})) and the affine part
+            // c_k = rb_k - B kff_k of the forward recursion, all stages in parallel
             for (int k = lane; k < N; k += 64) {
                 const double *rec = linb + (size_t)k * LIN_REC;
                 double g0 = gt[k * 10 + 8], g1 = gt[k * 10 + 9];
+                double Bk[16];
+#pragma unroll
+                for (int l = 0; l < 16; l++) Bk[l] = rec[64 + l];
 #pragma unroll
                 for (int l = 0; l < 8; l++) {
                     const double h = Prb[k * 8 + l] + pv[(k + 1) * 8 + l];
-                    g0 = fma(rec[64 + l * 2 + 0], h, g0);
-                    g1 = fma(rec[64 + l * 2 + 1], h, g1);
+                    g0 = fma(Bk[l * 2 + 0], h, g0);
+                    g1 = fma(Bk[l * 2 + 1], h, g1);
                 }
-                kff[k * 2 + 0] = Ginv[k * 4 + 0] * g0 + Ginv[k * 4 + 1] * g1;
-                kff[k * 2 + 1] = Ginv[k * 4 + 1] * g0 + Ginv[k * 4 + 2] * g1;
+                const double kf0 = Ginv[k * 4 + 0] * g0 + Ginv[k * 4 + 1] * g1;
+                const double kf1 = Ginv[k * 4 + 1] * g0 + Ginv[k * 4 + 2] * g1;
+                kff[k * 2 + 0] = kf0;
+                kff[k * 2 + 1] = kf1;
+#pragma unroll
+                for (int i = 0; i < 8; i++) dz[(k + 1) * 10 + i] = rb[k * 8 + i] - Bk[i * 2] * kf0 - Bk[i * 2 + 1] * kf1;
             }
             if (lane < 8) dz[lane] = 0.0;
             WSYNC();
 
-            // ---- forward recursion: dx_{k+1} = rb_k - B kff_k + (A - B K) dx_k ----
+            // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k ; lane (i, l) holds M_k[i][l] ----
             {
-                const int i = lane & 7;
-                stream_sweep<+1>(linb, stage2, N, lane, [&](int k, const double *AB) {
-                    const double b0 = AB[64 + i * 2], b1 = AB[64 + i * 2 + 1];
-                    double acc = rb[k * 8 + i] - b0 * kff[k * 2] - b1 * kff[k * 2 + 1];
-#pragma unroll
-                    for (int l = 0; l < 8; l++)
-                        acc = fma(AB[i * 8 + l] - b0 * Kl[k * 16 + l] - b1 * Kl[k * 16 + 8 + l], dz[k * 10 + l], acc);
-                    if (lane < 8) dz[(k + 1) * 10 + i] = acc;
+                const int i = lane >> 3, l = lane & 7;
+                stream_rows<+1, 8>(Mg, N, lane, [&](int k, double m) {
+                    const double t = sum8(m * dz[k * 10 + l]);
+                    if (l == 0) dz[(k + 1) * 10 + i] += t;
                     WSYNC();
                 });
             }
@@ -615,7 +687,7 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P;
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M; a.Mt = h->q_Mt;
     const int N = h->N, NS = h->NS;
     const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 10) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
     if (lds > 160 * 1024) return 1;
