@@ -111,21 +111,18 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int lane,
     double r[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const int kk = (DIR < 0) ? N - 1 - d : d;
-        r[d] = (d < N) ? rows[(size_t)kk * 64 + lane] : 0.0;
+        const int sd = min(d, N - 1);
+        r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sd : sd) * 64 + lane];
     }
     for (int s0 = 0; s0 < N; s0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int s = s0 + d;
-            if (s >= N) break;
             const int k = (DIR < 0) ? N - 1 - s : s;
             const double v = r[d];
-            if (s + D < N) {
-                const int kk = (DIR < 0) ? N - 1 - (s + D) : s + D;
-                r[d] = rows[(size_t)kk * 64 + lane];
-            }
-            body(k, v);
+            const int sn = min(s + D, N - 1);          // unconditional, clamped (see stream_sweep)
+            r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sn : sn) * 64 + lane];
+            if (s < N) body(k, v);
         }
     }
 }
@@ -148,13 +145,16 @@ __device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
 template <int DIR, int D, typename F>
 __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2, int N, int lane, F &&body)
 {
+    // All ring loads are UNCONDITIONAL (indices clamped into range): a load under a branch makes the
+    // compiler merge the ring registers through copies and wait for the load right where it is issued.
+    const int l2 = (lane < 24) ? 64 + lane : lane;       // second element of a record owned by this lane
     double ra[D], rb2[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const int kk = (DIR < 0) ? N - 1 - d : d;
-        const bool ok = d < N;
-        ra[d] = ok ? linb[(size_t)kk * LIN_REC + lane] : 0.0;
-        rb2[d] = (ok && lane < 24) ? linb[(size_t)kk * LIN_REC + 64 + lane] : 0.0;
+        const int sd = min(d, N - 1);
+        const int kk = (DIR < 0) ? N - 1 - sd : sd;
+        ra[d] = linb[(size_t)kk * LIN_REC + lane];
+        rb2[d] = linb[(size_t)kk * LIN_REC + l2];
     }
     stage2[lane] = ra[0];
     if (lane < 24) stage2[64 + lane] = rb2[0];
@@ -163,19 +163,18 @@ __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2,
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int s = s0 + d;
-            if (s >= N) break;
             const int k = (DIR < 0) ? N - 1 - s : s;
             double *cur = stage2 + (s & 1) * LIN_REC, *nxt = stage2 + ((s + 1) & 1) * LIN_REC;
-            if (s + 1 < N) {
-                nxt[lane] = ra[(d + 1) % D];
-                if (lane < 24) nxt[64 + lane] = rb2[(d + 1) % D];
+            const double na = ra[(d + 1) % D], nb = rb2[(d + 1) % D];
+            const int sn = min(s + D, N - 1);
+            const int kk = (DIR < 0) ? N - 1 - sn : sn;
+            ra[d] = linb[(size_t)kk * LIN_REC + lane];
+            rb2[d] = linb[(size_t)kk * LIN_REC + l2];
+            if (s < N) {
+                nxt[lane] = na;
+                if (lane < 24) nxt[64 + lane] = nb;
+                body(k, cur);
             }
-            if (s + D < N) {
-                const int kk = (DIR < 0) ? N - 1 - (s + D) : s + D;
-                ra[d] = linb[(size_t)kk * LIN_REC + lane];
-                if (lane < 24) rb2[d] = linb[(size_t)kk * LIN_REC + 64 + lane];
-            }
-            body(k, cur);
         }
     }
 }
@@ -313,6 +312,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         return acc;
     };
 
+/*@S:0*/
     // ------------------------------------------------------------------ initial point
     for (int e = lane; e < NS * 10; e += 64) z[e] = (e < 8) ? a.x0[(size_t)b * 8 + e] - xb[e] : 0.0;
     for (int e = lane; e < NS * 8; e += 64) pi[e] = 0.0;
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
     double dla_l[NSLOT], dla_u[NSLOT], dta_l[NSLOT], dta_u[NSLOT];
     for (it = 0;; it++) {
+/*@S:1*/
         // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
         for (int e = lane; e < NS * 12; e += 64) cf[e] = 0.0;
         WSYNC();
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             acc -= cf[k * 12 + j];
             gt[e] = acc;
         }
+/*@S:2*/
         // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
         // between stages: the loop runs at the pace of the LDS staging)
         stream_sweep<+1, 8>(linb, stage2, N, lane, [&](int k, const double *AB) {
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             WSYNC();
         });
+/*@S:3*/
         // (iii) masks and norms
         res_g = 0.0; res_b = 0.0;
         for (int e = lane; e < NS * 10; e += 64) {
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
         double alpha = 1.0, sigma = 0.0;
         for (int pass = 0; pass < 2; pass++) {
+/*@S:4*/
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
             for (int e = lane; e < NS * 12; e += 64) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
             WSYNC();
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             WSYNC();
 
+/*@S:5*/
             // ---- factorisation (pass 0 only): P_k, K_k, Guu^-1, P_{k+1} rb_k ----
             if (pass == 0) {
                 {   // terminal stage
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 });
             }
 
+/*@S:6*/
             // ---- vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) ----
             // the part without p_{k+1} for all stages in parallel ...
             for (int e = lane; e < NS * 8; e += 64) {
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 pv[e] = v;
             }
             WSYNC();
+/*@S:7*/
             // ... then one multiply + an 8-lane DPP sum per stage: lane (j, l) holds M_k[l][j]
             {
                 const int j = lane >> 3, l = lane & 7;
@@ -535,6 +542,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     WSYNC();
                 });
             }
+/*@S:8*/
             // feed-forward terms kff_k = Guu^-1 (gt_u + B'(P_{k+1} rb_k + p_{k+1})) and the affine part
             // c_k = rb_k - B kff_k of the forward recursion, all stages in parallel
             for (int k = lane; k < N; k += 64) {
@@ -559,6 +567,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             if (lane < 8) dz[lane] = 0.0;
             WSYNC();
 
+/*@S:9*/
             // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k ; lane (i, l) holds M_k[i][l] ----
             {
                 const int i = lane >> 3, l = lane & 7;
@@ -568,6 +577,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     WSYNC();
                 });
             }
+/*@S:10*/
             // inputs and costate steps of all stages in parallel
             const bool want_dpi = (pass == 1) || (a.m_act == 0);
             for (int e = lane; e < NS * 2; e += 64) {
@@ -591,6 +601,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             WSYNC();
 
+/*@S:11*/
             // ---- slack / multiplier steps, step length ----
             double amax = 1.0, mu_aff = 0.0;
 #pragma unroll
@@ -631,6 +642,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             WSYNC();
         }
+/*@S:12*/
         if (alpha < 1e-12) { qstatus = 2; break; }
         for (int e = lane; e < NS * 10; e += 64) z[e] = fma(alpha, dz[e], z[e]);
         for (int e = lane; e < NS * 8; e += 64) pi[e] = fma(alpha, pv[e], pi[e]);
@@ -644,6 +656,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     }
     if (qstatus == 1 && !(res_g <= 1e4 * tol_g && res_b <= 1e4 * tol_b && res_d <= 1e4 * tol_d && res_m <= 1e4 * tol_m)) qstatus = 4;
 
+/*@S:13*/
     // ------------------------------------------------------------------ RTI update
     int st = 0;
     if (qstatus == 3) st = 1;
