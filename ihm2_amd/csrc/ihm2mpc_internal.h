@@ -58,7 +58,6 @@ struct ihm2mpc_handle {
     double *lin;    // (B,N,88) linearisation records [A | B | b]
     // ---- QP workspace in HBM/L2 (everything else of the QP lives in LDS / registers) ----
     double *q_g;    // (B,NS,10) QP gradient
-    double *q_pi;   // (B,NS,8)  QP costates (accumulated; read only when residuals are re-evaluated)
     double *q_P;    // (B,NS,64) Riccati matrices of the current factorisation
     double *q_M, *q_Mt;   // (B,N,64) closed-loop matrices A - B K, row-major and transposed
     double *scratch;   // (B, 3*8) plant scratch

@@ -41,7 +41,7 @@ struct QpArgs {
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g, *P, *M, *Mt, *qpi;
+    double *g, *P, *M, *Mt;
 };
 
 #define INF_BOUND 1e20
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
     // ---- LDS carve-up (doubles) ----
     double *z = sm;                  // NS*10  QP iterate
-    double *gt = z + NS * 10;        // NS*10  modified gradient of the Newton system
-    double *rg = gt + NS * 10;       // NS*10  stationarity residual (evaluated, then scaled by 1 - alpha)
-    double *pv = rg + NS * 10;       // NS*8   Riccati vector p_k, then dpi_k
+    double *gt = z + NS * 10;        // NS*10  stationarity residual / modified gradient
+    double *pi = gt + NS * 10;       // NS*8   QP costates
+    double *pv = pi + NS * 8;        // NS*8   Riccati vector p_k, then dpi_k
     double *rb = pv + NS * 8;        // N*8    dynamics residual
     double *gam = rb + N * 8;        // NS*12  barrier weights per constraint slot
     double *cf = gam + NS * 12;      // NS*12  lam_l - lam_u, then gradient coefficients
@@ -211,7 +211,6 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *gb = a.g + (size_t)b * NS * 10;
     double *Pg = a.P + (size_t)b * NS * 64;
     double *Mg = a.M + (size_t)b * N * 64, *Mtg = a.Mt + (size_t)b * N * 64;
-    double *pi = a.qpi + (size_t)b * NS * 8;      // QP costates: only needed when residuals are (re-)evaluated
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 24;
 
@@ -334,92 +333,76 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
     double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
     double dla_l[NSLOT], dla_u[NSLOT], dta_l[NSLOT], dta_u[NSLOT];
-    // The linear residuals (rg, rb, rd) are evaluated from their definition at the first iteration; a
-    // damped Newton step multiplies them by (1 - alpha) exactly, so later iterations carry them as
-    // estimates scaled by (1 - alpha).  An exit is only taken on freshly evaluated residuals: when the
-    // estimates pass the test (or the iteration cap is hit) they are re-evaluated and the test repeated.
-    bool estimated = false;
     for (it = 0;; it++) {
-        int decided = -1;
-        for (int refresh = 0; refresh < 2; refresh++) {
 /*@S:1*/
-            if (!estimated) {
-                // ---- slack residuals; lam_l - lam_u -> cf ----
-                for (int e = lane; e < NS * 12; e += 64) cf[e] = 0.0;
-                WSYNC();
+        // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
+        for (int e = lane; e < NS * 12; e += 64) cf[e] = 0.0;
+        WSYNC();
+        double mu_acc = 0.0;
+        res_d = 0.0; res_m = 0.0;
 #pragma unroll
-                for (int r = 0; r < NSLOT; r++) {
-                    rd_l[r] = rd_u[r] = 0.0;
-                    if (s_kc[r] < 0) continue;
-                    const double rz = row_dot(s_kc[r], z);
-                    if (fin(s_dl[r])) rd_l[r] = rz - t_l[r] - s_dl[r];
-                    if (fin(s_du[r])) rd_u[r] = s_du[r] - rz - t_u[r];
-                    cf[s_kc[r]] = lam_l[r] - lam_u[r];
-                }
-                WSYNC();
-                // ---- stationarity and dynamics residuals ----
-                // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
-                for (int e = lane; e < NS * 10; e += 64) {
-                    const int k = e / 10, j = e % 10;
-                    double acc = gb[e];
-#pragma unroll
-                    for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
-                    if (k < N) {
-                        acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
-                        acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
-                    }
-                    if (j < 8) acc -= pi[k * 8 + j];
-                    acc -= cf[k * 12 + j];
-                    rg[e] = acc;
-                }
-/*@S:2*/
-                // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step
-                stream_sweep<+1, 4>(linb, stage2, N, lane, [&](int k, const double *AB) {
-                    if (lane < 10) {
-                        const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
-                        double acc = rg[k * 10 + lane];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], pi[(k + 1) * 8 + l], acc);
-                        rg[k * 10 + lane] = acc;
-                    } else if (lane >= 16 && lane < 24) {
-                        const int i = lane - 16;
-                        double acc = AB[80 + i] - z[(k + 1) * 10 + i];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(AB[i * 8 + l], z[k * 10 + l], acc);
-                        acc = fma(AB[64 + i * 2 + 0], z[k * 10 + 8], acc);
-                        acc = fma(AB[64 + i * 2 + 1], z[k * 10 + 9], acc);
-                        rb[k * 8 + i] = acc;
-                    }
-                    WSYNC();
-                });
-                // (iii) x_0 and the padded terminal inputs are not variables
-                if (lane < 8) rg[lane] = 0.0;
-                else if (lane < 10) rg[N * 10 + lane] = 0.0;
-                WSYNC();
-            }
-/*@S:3*/
-            // ---- norms; complementarity is always fresh ----
-            res_g = 0.0; res_b = 0.0; res_d = 0.0; res_m = 0.0;
-            double mu_acc = 0.0;
-            for (int e = lane; e < NS * 10; e += 64) res_g = nanmax(res_g, fabs(rg[e]));
-            for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e]));
-#pragma unroll
-            for (int r = 0; r < NSLOT; r++) {
-                if (s_kc[r] < 0) continue;
-                if (fin(s_dl[r])) { mu_acc += lam_l[r] * t_l[r]; res_m = nanmax(res_m, fabs(lam_l[r] * t_l[r])); }
-                if (fin(s_du[r])) { mu_acc += lam_u[r] * t_u[r]; res_m = nanmax(res_m, fabs(lam_u[r] * t_u[r])); }
-                res_d = nanmax(res_d, nanmax(fabs(rd_l[r]), fabs(rd_u[r])));
-            }
-            res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m);
-            mu = wave_sum(mu_acc) * inv_m;
-            const bool nan_ = !(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m);
-            const bool conv = res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m;
-            const bool wants_exit = nan_ || conv || it >= a.iter_max;
-            if (wants_exit && estimated) { estimated = false; continue; }      // re-evaluate, then decide
-            decided = nan_ ? 3 : (conv ? 0 : (it >= a.iter_max ? 1 : -1));
-            break;
+        for (int r = 0; r < NSLOT; r++) {
+            rd_l[r] = rd_u[r] = 0.0;
+            if (s_kc[r] < 0) continue;
+            const double rz = row_dot(s_kc[r], z);
+            const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+            if (al) { rd_l[r] = rz - t_l[r] - s_dl[r]; mu_acc += lam_l[r] * t_l[r]; res_m = nanmax(res_m, fabs(lam_l[r] * t_l[r])); }
+            if (au) { rd_u[r] = s_du[r] - rz - t_u[r]; mu_acc += lam_u[r] * t_u[r]; res_m = nanmax(res_m, fabs(lam_u[r] * t_u[r])); }
+            res_d = nanmax(res_d, nanmax(fabs(rd_l[r]), fabs(rd_u[r])));
+            cf[s_kc[r]] = lam_l[r] - lam_u[r];
         }
-        if (decided >= 0) { qstatus = decided; break; }
+        WSYNC();
+        // ---- stationarity and dynamics residuals ----
+        // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
+        for (int e = lane; e < NS * 10; e += 64) {
+            const int k = e / 10, j = e % 10;
+            double acc = gb[e];
+#pragma unroll
+            for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
+            if (k < N) {
+                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
+                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
+            }
+            if (j < 8) acc -= pi[k * 8 + j];
+            acc -= cf[k * 12 + j];
+            gt[e] = acc;
+        }
+/*@S:2*/
+        // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
+        // between stages: the loop runs at the pace of the LDS staging)
+        stream_sweep<+1, 8>(linb, stage2, N, lane, [&](int k, const double *AB) {
+            if (lane < 10) {
+                const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
+                double acc = gt[k * 10 + lane];
+#pragma unroll
+                for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], pi[(k + 1) * 8 + l], acc);
+                gt[k * 10 + lane] = acc;
+            } else if (lane >= 16 && lane < 24) {
+                const int i = lane - 16;
+                double acc = AB[80 + i] - z[(k + 1) * 10 + i];
+#pragma unroll
+                for (int l = 0; l < 8; l++) acc = fma(AB[i * 8 + l], z[k * 10 + l], acc);
+                acc = fma(AB[64 + i * 2 + 0], z[k * 10 + 8], acc);
+                acc = fma(AB[64 + i * 2 + 1], z[k * 10 + 9], acc);
+                rb[k * 8 + i] = acc;
+            }
+            WSYNC();
+        });
+/*@S:3*/
+        // (iii) masks and norms
+        res_g = 0.0; res_b = 0.0;
+        for (int e = lane; e < NS * 10; e += 64) {
+            const int k = e / 10, j = e % 10;
+            double v = gt[e];
+            if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
+            res_g = nanmax(res_g, fabs(v));
+        }
+        for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e]));
+        res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m);
+        mu = wave_sum(mu_acc) * inv_m;
+        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; }
+        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; }
+        if (it >= a.iter_max) { qstatus = 1; break; }
         WSYNC();
 
         double alpha = 1.0, sigma = 0.0;
@@ -447,7 +430,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             WSYNC();
             for (int e = lane; e < NS * 10; e += 64) {
                 const int k = e / 10, j = e % 10;
-                double acc = ((pass == 0) ? rg[e] : gt[e]) + cf[k * 12 + j];
+                double acc = gt[e] + cf[k * 12 + j];
                 if (k < N) {
                     acc = fma(a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
                     acc = fma(a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
@@ -661,20 +644,14 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         }
 /*@S:12*/
         if (alpha < 1e-12) { qstatus = 2; break; }
-        const double oma = 1.0 - alpha;
-        for (int e = lane; e < NS * 10; e += 64) { z[e] = fma(alpha, dz[e], z[e]); rg[e] *= oma; }
+        for (int e = lane; e < NS * 10; e += 64) z[e] = fma(alpha, dz[e], z[e]);
         for (int e = lane; e < NS * 8; e += 64) pi[e] = fma(alpha, pv[e], pi[e]);
-        for (int e = lane; e < N * 8; e += 64) rb[e] *= oma;
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
             if (fin(s_dl[r])) { lam_l[r] = fma(alpha, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
             if (fin(s_du[r])) { lam_u[r] = fma(alpha, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
-            rd_l[r] *= oma; rd_u[r] *= oma;
         }
-        // estimates only while the barrier parameter is far from the tolerance: in the final, ill-conditioned
-        // iterations the residuals are re-evaluated so that solve errors are corrected, not accumulated
-        estimated = mu > 1e3 * tol_m;
         WSYNC();
     }
     if (qstatus == 1 && !(res_g <= 1e4 * tol_g && res_b <= 1e4 * tol_b && res_d <= 1e4 * tol_d && res_m <= 1e4 * tol_m)) qstatus = 4;
@@ -723,9 +700,9 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M; a.Mt = h->q_Mt; a.qpi = h->q_pi;
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M; a.Mt = h->q_Mt;
     const int N = h->N, NS = h->NS;
-    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 10 + 8 + 12 + 12 + 10) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
+    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 10) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
     if (lds > 160 * 1024) return 1;
     const int per_lane = (h->nslots + 63) / 64;
     if (per_lane <= 5) {

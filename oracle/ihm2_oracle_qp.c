@@ -201,16 +201,9 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
             else { t[iu] = 1.0; lam[iu] = 0.0; }
         }
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
-    /* The linear residuals (rg, rb, rd) are evaluated from their definition at the first iteration;
-     * a damped Newton step multiplies them by (1 - alpha) exactly, so later iterations carry them as
-     * ESTIMATES scaled by (1 - alpha) instead of re-evaluating 3 matrix-vector passes per iteration.
-     * An exit is only ever taken on freshly evaluated residuals: when the estimates pass the test (or
-     * the iteration cap is hit) they are re-evaluated and the test is repeated. */
-    int estimated = 0;
     for (it = 0;; it++) {
-        for (int refresh = 0; refresh < 2; refresh++) {
-        if (!estimated) {
-        /* ---- residuals from their definition ---- */
+        /* ---- residuals ---- */
+        res_g = res_b = res_d = res_m = 0; mu = 0;
         for (int k = 0; k < NS; k++) {
             for (int c = 0; c < NC; c++) {
                 double rz = 0;
@@ -232,6 +225,7 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
                 if (k == 0 && j < NX) acc = 0; /* x_0 is not a variable */
                 if (k == N && j >= NX) acc = 0;
                 rg[k * NZ + j] = acc;
+                res_g = fmax(res_g, fabs(acc));
             }
             if (k < N)
                 for (int i = 0; i < NX; i++) {
@@ -239,35 +233,22 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
                     for (int l = 0; l < NX; l++) acc += A[(k * NX + i) * NX + l] * z[k * NZ + l];
                     for (int l = 0; l < NU; l++) acc += Bm[(k * NX + i) * NU + l] * z[k * NZ + NX + l];
                     rb[k * NX + i] = acc;
+                    res_b = fmax(res_b, fabs(acc));
                 }
             for (int c = 0; c < NC; c++) {
                 int il = k * 2 * NC + c, iu = il + NC;
                 rd[il] = act[il] ? (Rz[k * NC + c] - t[il] - dl[k * NC + c]) : 0.0;
                 rd[iu] = act[iu] ? (du[k * NC + c] - Rz[k * NC + c] - t[iu]) : 0.0;
+                res_d = fmax(res_d, fmax(fabs(rd[il]), fabs(rd[iu])));
+                if (act[il]) { mu += lam[il] * t[il]; res_m = fmax(res_m, fabs(lam[il] * t[il])); }
+                if (act[iu]) { mu += lam[iu] * t[iu]; res_m = fmax(res_m, fabs(lam[iu] * t[iu])); }
             }
         }
-        }
-        /* ---- norms (complementarity is always fresh) ---- */
-        res_g = res_b = res_d = res_m = 0; mu = 0;
-        for (int i = 0; i < NS * NZ; i++) res_g = fmax(res_g, fabs(rg[i]));
-        for (int i = 0; i < N * NX; i++) res_b = fmax(res_b, fabs(rb[i]));
-        for (int i = 0; i < NS * 2 * NC; i++) {
-            res_d = fmax(res_d, fabs(rd[i]));
-            if (act[i]) { mu += lam[i] * t[i]; res_m = fmax(res_m, fabs(lam[i] * t[i])); }
-        }
         if (m_act > 0) mu /= m_act;
-        if (orc_debug) fprintf(stderr, "ipm it %2d%s res_g %.3e res_b %.3e res_d %.3e res_m %.3e mu %.3e\n", it, estimated ? "~" : " ", res_g, res_b, res_d, res_m, mu);
-        {
-            int nan_ = !(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m);
-            int conv = res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m;
-            int wants_exit = nan_ || conv || it >= iter_max;
-            if (wants_exit && estimated) { estimated = 0; continue; }   /* re-evaluate, then decide */
-            if (nan_) status = 3; else if (conv) status = 0; else if (it >= iter_max) status = 1; else status = -1;
-        }
-        break;
-        }
-        if (status >= 0) break;
-        status = 1;
+        if (orc_debug) fprintf(stderr, "ipm it %2d res_g %.3e res_b %.3e res_d %.3e res_m %.3e mu %.3e\n", it, res_g, res_b, res_d, res_m, mu);
+        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { status = 3; break; }
+        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { status = 0; break; }
+        if (it >= iter_max) { status = 1; break; }
 
         /* ---- barrier-augmented Hessian ---- */
         for (int k = 0; k < NS; k++) {
@@ -347,12 +328,6 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
         }
         for (int i = 0; i < NS * 2 * NC; i++)
             if (act[i]) { lam[i] += alpha * dlam[i]; t[i] += alpha * dt[i]; }
-        for (int i = 0; i < NS * NZ; i++) rg[i] *= 1.0 - alpha;
-        for (int i = 0; i < N * NX; i++) rb[i] *= 1.0 - alpha;
-        for (int i = 0; i < NS * 2 * NC; i++) rd[i] *= 1.0 - alpha;
-        /* estimates only while the barrier parameter is far from the tolerance: in the final, ill-conditioned
-         * iterations the residuals are re-evaluated so that solve errors are corrected, not accumulated */
-        estimated = mu > 1e3 * tol_m;
     }
     /* max-iter exits that are converged to the loose tolerance (1e4 x tol) are reported as status 1
        ("acceptable": acados RTI tolerates ACADOS_MAXITER from the QP); otherwise status 4 = failed */
