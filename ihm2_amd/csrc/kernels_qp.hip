@@ -369,25 +369,28 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         }
 /*@S:2*/
         // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
-        // between stages: the loop runs at the pace of the LDS staging)
-        stream_sweep<+1, 8>(linb, stage2, N, lane, [&](int k, const double *AB) {
-            if (lane < 10) {
-                const int cj = (lane < 8) ? lane : 64 + (lane - 8), sj = (lane < 8) ? 8 : 2;
-                double acc = gt[k * 10 + lane];
+        // between stages).  Branch-free: every lane forms one product of each 8x8 part and the 8-term sums
+        // are DPP reductions -- lane (o, l): A[l][o] pi_{k+1}[l] (column o of A) and A[o][l] z_k[l] (row o).
+        {
+            const int o = lane >> 3, l = lane & 7;
+            stream_sweep<+1, 4>(linb, stage2, N, lane, [&](int k, const double *AB) {
+                const double tp = sum8(AB[l * 8 + o] * pi[(k + 1) * 8 + l]);
+                const double tz = sum8(AB[o * 8 + l] * z[k * 10 + l]);
+                // the two input columns / rows: lanes (o, 0) add B-terms to rb, lanes (0,1),(1,1) do B' pi
+                double bp = 0.0;
+                if (l == 1 && o < 2) {
 #pragma unroll
-                for (int l = 0; l < 8; l++) acc = fma(AB[cj + l * sj], pi[(k + 1) * 8 + l], acc);
-                gt[k * 10 + lane] = acc;
-            } else if (lane >= 16 && lane < 24) {
-                const int i = lane - 16;
-                double acc = AB[80 + i] - z[(k + 1) * 10 + i];
-#pragma unroll
-                for (int l = 0; l < 8; l++) acc = fma(AB[i * 8 + l], z[k * 10 + l], acc);
-                acc = fma(AB[64 + i * 2 + 0], z[k * 10 + 8], acc);
-                acc = fma(AB[64 + i * 2 + 1], z[k * 10 + 9], acc);
-                rb[k * 8 + i] = acc;
-            }
-            WSYNC();
-        });
+                    for (int q = 0; q < 8; q++) bp = fma(AB[64 + q * 2 + o], pi[(k + 1) * 8 + q], bp);
+                }
+                if (l == 0) {
+                    gt[k * 10 + o] += tp;
+                    rb[k * 8 + o] = tz + AB[80 + o] - z[(k + 1) * 10 + o] + AB[64 + o * 2] * z[k * 10 + 8] + AB[64 + o * 2 + 1] * z[k * 10 + 9];
+                } else if (l == 1 && o < 2) {
+                    gt[k * 10 + 8 + o] += bp;
+                }
+                WSYNC();
+            });
+        }
 /*@S:3*/
         // (iii) masks and norms
         res_g = 0.0; res_b = 0.0;
