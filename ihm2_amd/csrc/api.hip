@@ -116,7 +116,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     if (cfg->batch < 1) return fail("batch must be >= 1");
     if (cfg->N < 2 || cfg->N > IHM2MPC_NMAX) return fail("N must be in [2, %d]", IHM2MPC_NMAX);
     if (cfg->M < 1) return fail("M must be >= 1");
-    if (cfg->model != IHM2MPC_MODEL_FKIN6) return fail("OCP model %d is not implemented (only fkin6)", cfg->model);
+    if (cfg->model != IHM2MPC_MODEL_FKIN6 && cfg->model != IHM2MPC_MODEL_FDYN6) return fail("unknown OCP model %d", cfg->model);
     if (cfg->ntracks < 1 || cfg->nknots < 2) return fail("need at least one track table with >= 2 knots");
     if (!(cfg->dt > 0.0)) return fail("dt must be positive");
     int ndev = 0;

@@ -8,8 +8,8 @@
 //
 // Mapping: one lane per (b, k) pair, k fastest (instance-major arrays): a wavefront reads 64
 // consecutive 64-byte state rows (4 KB contiguous) and writes 64 consecutive 704-byte records.
-// Sensitivities are held column-wise in registers; only the 52 structurally non-zero entries of the
-// 8x10 matrix are stored and only the 31 non-zeros of the model Jacobian are multiplied
+// Sensitivities are held column-wise in registers; only the structurally non-zero entries of the
+// 8x10 matrix are stored (52 for fkin6, 55 for fdyn6) and only the non-zeros of the model Jacobian (31 / 37) are multiplied
 // (model.hpp: JX_MASK / S_COL_MASK).  Algorithmic traffic per pair: read 10 + 8 doubles, write 88.
 #include "ihm2mpc_internal.h"
 #include "model.hpp"
@@ -19,11 +19,11 @@ using namespace ihm2;
 namespace {
 
 // one RK4 stage of sensitivity column COL:  dX = S + ah*dK_prev ; dK = Jx dX + Ju[:,COL] ; Sacc += wh*dK
-template <int COL>
+template <int MODEL, int COL>
 __device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const double (&S)[8], double (&Sacc)[8],
                                                double (&dK)[8], double ah, double wh)
 {
-    constexpr unsigned cm = S_COL_MASK[COL];
+    constexpr unsigned cm = S_COL_MASK[MODEL][COL];
     double dX[8];
 #pragma unroll
     for (int l = 0; l < 8; l++)
@@ -32,10 +32,10 @@ __device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const d
     for (int i = 0; i < 8; i++) {
         if (!((cm >> i) & 1u)) continue;
         double acc = 0.0;
-        if (COL >= 8 && ((JU_MASK[i] >> (COL - 8)) & 1u)) acc = J[i][COL];
+        if (COL >= 8 && ((JU_MASK[MODEL][i] >> (COL - 8)) & 1u)) acc = J[i][COL];
 #pragma unroll
         for (int l = 0; l < 8; l++)
-            if (((JX_MASK[i] & cm) >> l) & 1u) acc = fma(J[i][l], dX[l], acc);
+            if (((JX_MASK[MODEL][i] & cm) >> l) & 1u) acc = fma(J[i][l], dX[l], acc);
         dK[i] = acc;
     }
 #pragma unroll
@@ -43,10 +43,10 @@ __device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const d
         if ((cm >> i) & 1u) Sacc[i] = fma(wh, dK[i], Sacc[i]);
 }
 
-template <int COL>
+template <int MODEL, int COL>
 __device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&dst)[8])
 {
-    constexpr unsigned cm = S_COL_MASK[COL];
+    constexpr unsigned cm = S_COL_MASK[MODEL][COL];
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if ((cm >> i) & 1u) dst[i] = src[i];
@@ -54,7 +54,8 @@ __device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&d
 
 #define FOR_ALL_COLS(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9)
 
-__global__ __launch_bounds__(64) void k_linearize_fkin6(
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_linearize(
     int B, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
     const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *__restrict__ xs,
     const double *__restrict__ us, double *__restrict__ lin)
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64) void k_linearize_fkin6(
         double xacc[8], K[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
-#define COPY_S_TO_ACC(c) sens_col_copy<c>(S[c], Sacc[c]);
+#define COPY_S_TO_ACC(c) sens_col_copy<MODEL, c>(S[c], Sacc[c]);
         FOR_ALL_COLS(COPY_S_TO_ACC)
 #pragma unroll 1
         for (int st = 0; st < 4; st++) {
@@ -95,15 +96,16 @@ __global__ __launch_bounds__(64) void k_linearize_fkin6(
             double X[8], J[8][10];
 #pragma unroll
             for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
-            fkin6_eval<true>(X, u_T, u_d, trk, K, J);
+            if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, K, J);
+            else fdyn6_eval<true>(X, u_T, u_d, trk, K, J);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
-#define STAGE_COL(c) sens_col_stage<c>(J, S[c], Sacc[c], dK[c], ah, wh);
+#define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sacc[c], dK[c], ah, wh);
             FOR_ALL_COLS(STAGE_COL)
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) x[i] = xacc[i];
-#define COPY_ACC_TO_S(c) sens_col_copy<c>(Sacc[c], S[c]);
+#define COPY_ACC_TO_S(c) sens_col_copy<MODEL, c>(Sacc[c], S[c]);
         FOR_ALL_COLS(COPY_ACC_TO_S)
     }
 
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(64) void k_linearize_fkin6(
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[j] >> i) & 1u) ? S[j][i] : 0.0;
+        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL][j] >> i) & 1u) ? S[j][i] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
+        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL][8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
         rec[80 + i] = x[i] - xk[8 + i];
     }
 }
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double
 #pragma unroll
             for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
             if (mdl == IHM2MPC_MODEL_FKIN6) fkin6_eval<false>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval(X, u_T, u_d, trk, K);
+            else fdyn6_eval<false>(X, u_T, u_d, trk, K, J);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
         }
@@ -172,8 +174,12 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
 {
     const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
-    hipLaunchKernelGGL(k_linearize_fkin6, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
-                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
+    if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
+        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+                           h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
+    else
+        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FKIN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+                           h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
 }
 
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn)

@@ -167,85 +167,171 @@ __device__ __forceinline__ void fkin6_eval(const double (&x)[8], double u_T, dou
     }
 }
 
-// Structural pattern of d f_i / d x_l (bit l of JX_MASK[i]) and of d f_i / d u (bit 0: u_T, bit 1: u_delta)
-__device__ constexpr unsigned JX_MASK[8] = {0x1Fu, 0x1Cu, 0x3Fu, 0xD8u, 0xC8u, 0xC8u, 0x40u, 0x80u};
-__device__ constexpr unsigned JU_MASK[8] = {0u, 0u, 0u, 2u, 2u, 2u, 1u, 2u};
+// Structural pattern of d f_i / d x_l (bit l of JX_MASK[model][i]) and of d f_i / d u (bit 0: u_T, bit 1: u_delta).
+// fdyn6: rows 3..5 (v_x_dot, v_y_dot, r_dot) depend on (v_x, v_y, r, T, delta) and on no input directly.
+__device__ constexpr unsigned JX_MASK[2][8] = {{0x1Fu, 0x1Cu, 0x3Fu, 0xD8u, 0xC8u, 0xC8u, 0x40u, 0x80u},
+                                               {0x1Fu, 0x1Cu, 0x3Fu, 0xF8u, 0xF8u, 0xF8u, 0x40u, 0x80u}};
+__device__ constexpr unsigned JU_MASK[2][8] = {{0u, 0u, 0u, 2u, 2u, 2u, 1u, 2u}, {0u, 0u, 0u, 0u, 0u, 0u, 1u, 2u}};
 // Rows of the sensitivity matrix S = d x_m / d (x_0, u) that can be non-zero in column j
 // (block-triangular structure): columns s0,n0,psi0 | v_x0,v_y0 | r0 | T0 | delta0 | u_T | u_delta
-__device__ constexpr unsigned S_COL_MASK[10] = {0x07u, 0x07u, 0x07u, 0x3Fu, 0x3Fu, 0x27u, 0x7Fu, 0xBFu, 0x7Fu, 0xBFu};
+__device__ constexpr unsigned S_COL_MASK[2][10] = {{0x07u, 0x07u, 0x07u, 0x3Fu, 0x3Fu, 0x27u, 0x7Fu, 0xBFu, 0x7Fu, 0xBFu},
+                                                   {0x07u, 0x07u, 0x07u, 0x3Fu, 0x3Fu, 0x3Fu, 0x7Fu, 0xBFu, 0x7Fu, 0xBFu}};
 
-// ---- fdyn6 (plant): explicit xdot ----
-__device__ __forceinline__ double lat_pacejka(double alpha) {
+// ---- forward-mode dual numbers (value + ND directional derivatives) for the fdyn6 force model ----
+template <int ND>
+struct Dual {
+    double v;
+    double d[ND];
+};
+template <int ND> __device__ __forceinline__ Dual<ND> mk_const(double c) { Dual<ND> r; r.v = c; for (int i = 0; i < ND; i++) r.d[i] = 0.0; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> mk_var(double c, int idx) { Dual<ND> r = mk_const<ND>(c); r.d[idx] = 1.0; return r; }
+#define DUAL_UNARY(name, fv, dfv)                                                   \
+    template <int ND> __device__ __forceinline__ Dual<ND> name(const Dual<ND> &a)  \
+    {                                                                               \
+        Dual<ND> r; const double x = a.v; const double f = (fv); const double df = (dfv); (void)f; \
+        r.v = f;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = df * a.d[i];        \
+        return r;                                                                   \
+    }
+DUAL_UNARY(msin, sin(x), cos(x))
+DUAL_UNARY(mcos, cos(x), -sin(x))
+DUAL_UNARY(matan, atan(x), 1.0 / (1.0 + x * x))
+DUAL_UNARY(mtanh, tanh(x), 1.0 - f * f)
+DUAL_UNARY(mexp, exp(x), f)
+DUAL_UNARY(msqrt, sqrt(x), 0.5 / f)
+DUAL_UNARY(mtan, tan(x), 1.0 + f * f)
+#undef DUAL_UNARY
+__device__ __forceinline__ double msin(double x) { return sin(x); }
+__device__ __forceinline__ double mcos(double x) { return cos(x); }
+__device__ __forceinline__ double matan(double x) { return atan(x); }
+__device__ __forceinline__ double mtanh(double x) { return tanh(x); }
+__device__ __forceinline__ double mexp(double x) { return exp(x); }
+__device__ __forceinline__ double msqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double mtan(double x) { return tan(x); }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; r.v = a.v + b.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; r.v = a.v - b.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND> &a) { Dual<ND> r; r.v = -a.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = -a.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; r.v = a.v * b.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = fma(a.v, b.d[i], a.d[i] * b.v); return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; const double ib = 1.0 / b.v; r.v = a.v * ib; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND> &a, double c) { Dual<ND> r = a; r.v += c; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(double c, const Dual<ND> &a) { return a + c; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND> &a, double c) { Dual<ND> r = a; r.v -= c; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(double c, const Dual<ND> &a) { return (-a) + c; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND> &a, double c) { Dual<ND> r; r.v = a.v * c; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * c; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(double c, const Dual<ND> &a) { return a * c; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND> &a, double c) { return a * (1.0 / c); }
+template <int ND> __device__ __forceinline__ Dual<ND> operator/(double c, const Dual<ND> &a) { return mk_const<ND>(c) / a; }
+__device__ __forceinline__ double val(double a) { return a; }
+template <int ND> __device__ __forceinline__ double val(const Dual<ND> &a) { return a.v; }
+
+// ---- fdyn6: Frenet 4-wheel Pacejka model (python/models.py:455-606), explicit form ----
+// The tyre/chassis force model maps (v_x, v_y, r, T, delta) to (v_x_dot, v_y_dot, r_dot).  It is written once
+// over a scalar type T: double for the plant, Dual<5> for the OCP (15 Jacobian entries by forward AD).
+template <typename T>
+__device__ __forceinline__ T lat_pacejka_t(const T &alpha)
+{
     const double BCDa = k_b1a * sin(2.0 * atan(k_static_weight / k_b2a));
     const double Ca = k_c1a, Da = k_d1a * k_static_weight + k_d2a, Ea = k_e1a * k_static_weight + k_e2a;
     const double Ba = BCDa / (Ca * Da);
-    const double Bx = Ba * alpha;
-    return Da * sin(Ca * atan(Bx - Ea * (Bx - atan(Bx))));
+    const T Bx = alpha * Ba;
+    return msin(matan(Bx - (Bx - matan(Bx)) * Ea) * Ca) * Da;
 }
-__device__ __forceinline__ double smooth_abs_nonzero(double v) { return tanh(10.0 * v) * v + 1e-6 * exp(-v * v); }
+template <typename T>
+__device__ __forceinline__ T smooth_abs_nonzero_t(const T &v) { return mtanh(v * 10.0) * v + mexp(-(v * v)) * 1e-6; }
 
-__device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8])
+template <typename T>
+__device__ inline void fdyn6_forces(const T &v_x, const T &v_y, const T &r, const T &Tq, const T &delta, T &vxd, T &vyd, T &rd)
+{
+    const T sd = msin(delta), cd = mcos(delta);
+    const T F_down = v_x * v_x * (0.5 * k_Cdown);
+    const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track;
+    const T base = F_down * 0.25 + k_static_weight;
+    const double hx = 0.5 * k_axle_track;
+    const T v_x_FL = v_x - r * hx, v_x_FR = v_x + r * hx, v_y_F = v_y + r * k_lF;
+    const T v_lon_FL = cd * v_x_FL + sd * v_y_F, v_lon_FR = cd * v_x_FR + sd * v_y_F;
+    const T v_lat_FL = cd * v_y_F - sd * v_x_FL, v_lat_FR = cd * v_y_F - sd * v_x_FR;
+    const T v_lat_R = v_y - r * k_lR;
+    // slip angles: atan2(y, x) with x = smooth_abs_nonzero(.) > 0  ->  atan(y / x)
+    const T a_FL = matan(v_lat_FL / smooth_abs_nonzero_t(v_lon_FL));
+    const T a_FR = matan(v_lat_FR / smooth_abs_nonzero_t(v_lon_FR));
+    const T a_RL = matan(v_lat_R / smooth_abs_nonzero_t(v_x_FL));      // v_lon_RL = v_x - hx r
+    const T a_RR = matan(v_lat_R / smooth_abs_nonzero_t(v_x_FR));      // v_lon_RR = v_x + hx r
+    // crossed slip angles exactly as models.py:543-546 (quirk Q3); order FL, FR, RL, RR
+    const T glat0 = lat_pacejka_t(a_RR), glat1 = lat_pacejka_t(a_RL), glat2 = lat_pacejka_t(a_FR), glat3 = lat_pacejka_t(a_FL);
+    const T F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
+    const T beta = matan(mtan(delta) * k_rwd);
+    const T r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
+    const T dtau = (r_kin - r) * k_Ktv;
+    const T denom = F_down * (-0.25) - k_m * k_g;
+    const T gm = (Tq - dtau) * k_Cm0 / denom, gp = (Tq + dtau) * k_Cm0 / denom;      // glon: FL, RL = gm ; FR, RR = gp
+    const T cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;   // FL
+    const T cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;   // FR
+    const T cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
+    const T cz2 = -(gm * hx) - glat2 * k_lR, cz3 = gp * hx - glat3 * k_lR;
+    // m a_x = X0 + Xx a_x + Xy a_y ; m a_y = Y0 + Yx a_x + Yy a_y with F_z,k = -(base + sx_k cx a_x + sy_k cy a_y),
+    // sx = (-,-,+,+), sy = (+,-,+,-)
+    const T sumx = cx0 + cx1 + gm + gp, sumy = cy0 + cy1 + glat2 + glat3;
+    const T X0 = F_drag - sumx * base, Y0 = -(sumy * base);
+    const T Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
+    const T Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
+    const T a11 = -Xx + k_m, a12 = -Xy, a21 = -Yx, a22 = -Yy + k_m;
+    const T det = a11 * a22 - a12 * a21;
+    const T a_x = (X0 * a22 - a12 * Y0) / det;
+    const T a_y = (a11 * Y0 - a21 * X0) / det;
+    const T lx = a_x * cx, ly = a_y * cy;
+    const T Fz0 = -(base - lx + ly), Fz1 = -(base - lx - ly), Fz2 = -(base + lx + ly), Fz3 = -(base + lx - ly);
+    const T Mz = cz0 * Fz0 + cz1 * Fz1 + cz2 * Fz2 + cz3 * Fz3;
+    vxd = a_x + v_y * r;
+    vyd = a_y - v_x * r;
+    rd = Mz * (1.0 / k_Iz);
+}
+
+// xdot (and with WITH_JAC the structural non-zeros of its Jacobian, pattern JX_MASK[1] / JU_MASK[1])
+template <bool WITH_JAC>
+__device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
 {
     const double n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
-    double sd, cd;
-    sincos(delta, &sd, &cd);
-    const double F_down = 0.5 * k_Cdown * v_x * v_x;
-    const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track;
-    const double base = k_static_weight + 0.25 * F_down;
-    const double sxv[4] = {-1.0, -1.0, 1.0, 1.0}, syv[4] = {1.0, -1.0, 1.0, -1.0};   // FL FR RL RR
-    const double hx = 0.5 * k_axle_track;
-    const double v_x_FL = v_x - hx * r, v_x_FR = v_x + hx * r, v_y_F = v_y + k_lF * r;
-    const double v_lon_FL = cd * v_x_FL + sd * v_y_F, v_lon_FR = cd * v_x_FR + sd * v_y_F;
-    const double v_lat_FL = -sd * v_x_FL + cd * v_y_F, v_lat_FR = -sd * v_x_FR + cd * v_y_F;
-    const double v_lon_RL = v_x - hx * r, v_lon_RR = v_x + hx * r, v_lat_R = v_y - k_lR * r;
-    const double a_FL = atan2(v_lat_FL, smooth_abs_nonzero(v_lon_FL));
-    const double a_FR = atan2(v_lat_FR, smooth_abs_nonzero(v_lon_FR));
-    const double a_RL = atan2(v_lat_R, smooth_abs_nonzero(v_lon_RL));
-    const double a_RR = atan2(v_lat_R, smooth_abs_nonzero(v_lon_RR));
-    // crossed slip angles exactly as models.py:543-546 (quirk Q3)
-    const double glat[4] = {lat_pacejka(a_RR), lat_pacejka(a_RL), lat_pacejka(a_FR), lat_pacejka(a_FL)};
-    const double F_drag = -(k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x) * tanh(10.0 * v_x);
-    const double beta = atan(k_rwd * tan(delta));
-    const double r_kin = sqrt(v_x * v_x + v_y * v_y) * sin(beta) / k_lR;
-    const double dtau = k_Ktv * (r_kin - r);
-    const double denom = -k_m * k_g - 0.25 * F_down;
-    const double gm = k_Cm0 * (T - dtau) / denom, gp = k_Cm0 * (T + dtau) / denom;
-    const double glon[4] = {gm, gp, gm, gp};
-    double cxk[4], cyk[4], czk[4];
-    cxk[0] = glon[0] * cd - glat[0] * sd; cyk[0] = glon[0] * sd + glat[0] * cd;
-    cxk[1] = glon[1] * cd - glat[1] * sd; cyk[1] = glon[1] * sd + glat[1] * cd;
-    cxk[2] = glon[2]; cyk[2] = glat[2];
-    cxk[3] = glon[3]; cyk[3] = glat[3];
-    czk[0] = -cxk[0] * hx + cyk[0] * k_lF;
-    czk[1] = cxk[1] * hx + cyk[1] * k_lF;
-    czk[2] = -glon[2] * hx - glat[2] * k_lR;
-    czk[3] = glon[3] * hx - glat[3] * k_lR;
-    double X0 = F_drag, Xx = 0, Xy = 0, Y0 = 0, Yx = 0, Yy = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        X0 -= cxk[k] * base; Xx -= cxk[k] * (sxv[k] * cx); Xy -= cxk[k] * (syv[k] * cy);
-        Y0 -= cyk[k] * base; Yx -= cyk[k] * (sxv[k] * cx); Yy -= cyk[k] * (syv[k] * cy);
-    }
-    const double a11 = k_m - Xx, a12 = -Xy, a21 = -Yx, a22 = k_m - Yy;
-    const double det = a11 * a22 - a12 * a21;
-    const double a_x = (X0 * a22 - a12 * Y0) / det;
-    const double a_y = (a11 * Y0 - a21 * X0) / det;
-    double Mz = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) Mz += czk[k] * -(base + sxv[k] * cx * a_x + syv[k] * cy * a_y);
     double dk;
     const double kap = trk.kappa(x[0], dk);
     double sp, cp;
     sincos(psi, &sp, &cp);
-    const double s_dot = (v_x * cp - v_y * sp) / (1.0 + kap * n);
+    const double num = v_x * cp - v_y * sp;
+    const double inv_dn = 1.0 / (1.0 + kap * n);
+    const double s_dot = num * inv_dn;
     f[0] = s_dot;
     f[1] = v_x * sp + v_y * cp;
     f[2] = r - kap * s_dot;
-    f[3] = a_x + v_y * r;
-    f[4] = a_y - v_x * r;
-    f[5] = Mz / k_Iz;
     f[6] = (u_T - T) * (1.0 / k_tT);
     f[7] = (u_delta - delta) * (1.0 / k_tdelta);
+    if (WITH_JAC) {
+        typedef Dual<5> D5;
+        D5 o0, o1, o2;
+        fdyn6_forces<D5>(mk_var<5>(v_x, 0), mk_var<5>(v_y, 1), mk_var<5>(r, 2), mk_var<5>(T, 3), mk_var<5>(delta, 4), o0, o1, o2);
+        f[3] = o0.v; f[4] = o1.v; f[5] = o2.v;
+#pragma unroll
+        for (int c = 0; c < 5; c++) { J[3][3 + c] = o0.d[c]; J[4][3 + c] = o1.d[c]; J[5][3 + c] = o2.d[c]; }
+        const double q = -s_dot * inv_dn;
+        J[0][0] = q * dk * n;
+        J[0][1] = q * kap;
+        J[0][2] = (-v_x * sp - v_y * cp) * inv_dn;
+        J[0][3] = cp * inv_dn;
+        J[0][4] = -sp * inv_dn;
+        J[1][2] = num;
+        J[1][3] = sp;
+        J[1][4] = cp;
+        J[2][0] = -dk * s_dot - kap * J[0][0];
+        J[2][1] = -kap * J[0][1];
+        J[2][2] = -kap * J[0][2];
+        J[2][3] = -kap * J[0][3];
+        J[2][4] = -kap * J[0][4];
+        J[2][5] = 1.0;
+        J[6][6] = -1.0 / k_tT;
+        J[6][8] = 1.0 / k_tT;
+        J[7][7] = -1.0 / k_tdelta;
+        J[7][9] = 1.0 / k_tdelta;
+    } else {
+        fdyn6_forces<double>(v_x, v_y, r, T, delta, f[3], f[4], f[5]);
+    }
 }
 
 }  // namespace ihm2

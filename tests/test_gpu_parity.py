@@ -195,3 +195,53 @@ def test_api_misuse_is_reported(track):
     with pytest.raises(_lib.Ihm2mpcError):
         s.set_tracks(bad, track.kappa_ref)
     s.free()
+
+
+# ---- dynamic (Pacejka) bicycle as the OCP model: BASELINE.json configs 3-4 without the soft path constraints ----
+@pytest.fixture(scope="module")
+def setup_dyn(track):
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    B = 40
+    ocp = make_ocp(model="fdyn6")
+    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, B, seed=77)
+    x0[:, 3] = np.linspace(4.0, 14.0, B)
+    solver.set_x0(x0)
+    solver.init_guess()          # kinematic Stanley rollout: a guess, the dynamic model sees defects
+    return dict(solver=solver, P=P, x0=x0, B=B)
+
+
+def test_fdyn6_linearize_matches_oracle(setup_dyn):
+    s, P = setup_dyn["solver"], setup_dyn["P"]
+    x, u = s.get_x(), s.get_u()
+    s.linearize()
+    A, Bm, b = s.get_linearization()
+    Ao, Bo, bo = P.linearize(x, u)
+    colscale = np.maximum(np.abs(Ao).max(axis=2, keepdims=True), 1e-30)
+    assert np.max(np.abs(A - Ao) / colscale) < 1e-9
+    colscale = np.maximum(np.abs(Bo).max(axis=2, keepdims=True), 1e-30)
+    assert np.max(np.abs(Bm - Bo) / colscale) < 1e-9
+    assert np.max(np.abs(b - bo)) < 1e-10
+    assert np.all(A[:, :, 3:, :3] == 0) and np.all(A[:, :, 6:, :6] == 0)
+    assert np.any(A[:, :, 3:6, 5] != 0)        # unlike fkin6, the yaw rate feeds back into the velocities
+
+
+def test_fdyn6_rti_step_matches_oracle(setup_dyn):
+    s, P, B, x0 = setup_dyn["solver"], setup_dyn["P"], setup_dyn["B"], setup_dyn["x0"]
+    x, u = s.get_x(), s.get_u()
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+    s.set_yref(yref); s.set_yref_e(yref_e); s.set_multipliers(None, None)
+    status = s.solve()
+    xg, ug = s.get_x(), s.get_u()
+    out = P.rti_step(x, u, x0, yref, yref_e)
+    assert np.mean(status == out["status"]) >= 0.95
+    ok = (status == 0) & (out["status"] == 0)
+    # from a kinematic rollout the slow instances give the dynamic model infeasible QPs: both sides report 4
+    assert ok.sum() >= 0.5 * B
+    assert _rel(xg[ok], x[ok]) < 1e-6          # tolerance 1e-6 relative (north star: 1e-5)
+    assert _rel(ug[ok], u[ok]) < 1e-6
+    assert _rel(s.get_residuals(), out["res"]) < 1e-8
