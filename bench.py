@@ -210,7 +210,7 @@ def main():
         f_lin, f_qp = flops_per_solve(n_ipm)
         ms_lin, ms_qp = t_lin / args.steps, t_qp / args.steps
         if ms_lin >= ms_qp:
-            kname, kms, kflops = "k_linearize_fkin6", ms_lin, f_lin * B
+            kname, kms, kflops = "k_linearize", ms_lin, f_lin * B
         else:
             kname, kms, kflops = "k_qp_wave", ms_qp, f_qp * B
         achieved = kflops / (kms * 1e-3) / 1e12

@@ -104,6 +104,7 @@ class IHM2Controller(Controller):
         sim_method_num_steps: int = 25,
         nlp_solver_type: str = "SQP_RTI",
         nlp_solver_max_iter: int = 1,
+        terminal_bounds: str = "reference",
     ) -> None:
         self.Nf, self.dt, self.s_target, self.B = Nf, dt, s_target, int(batch_size)
         self.config = Controller.Config(horizon_size=Nf, sampling_time=dt)
@@ -113,6 +114,14 @@ class IHM2Controller(Controller):
         model = get_acados_model_from_explicit_dynamics(
             name="ihm2_fkin6", continuous_model_fn=fkin6_model, x=self.nx, u=self.nu, p=2 * s_ref.shape[1])
         ocp = get_acados_ocp(model, Nf, n_max, v_x_max, T_max, delta_max, T_dot_max, delta_dot_max)
+        if terminal_bounds == "stage":
+            # quirk Q1: python/mpc.py:82-84 puts the T/delta limits on (v_y, r) at the terminal stage; with a plant
+            # whose yaw rate is real (|r| = |v kappa| > delta_max) that box is infeasible.  "stage" repeats the
+            # stage box [n, v_x, T, delta] at the terminal stage instead.
+            c = ocp.constraints
+            c.idxbx_e, c.lbx_e, c.ubx_e = c.idxbx.copy(), c.lbx.copy(), c.ubx.copy()
+        elif terminal_bounds != "reference":
+            raise ValueError("terminal_bounds must be 'reference' or 'stage'")
         opts = AcadosOcpOptions()                      # python/main.py:227-238, with ERK x M for IRK
         opts.tf = Nf * dt
         opts.nlp_solver_type = nlp_solver_type
@@ -155,6 +164,12 @@ class IHM2Controller(Controller):
             return None if bad[0] else u0[0]
         u0[bad] = np.nan
         return u0
+
+    def warm_start(self, x0: np.ndarray, v_ref_scale: float = 1.0) -> None:
+        """Replace the cold-start prediction (a car at rest at s = -6, ``python/main.py:242-246``) by a rollout of the
+        model from ``x0`` under Stanley feedback -- for batches that start anywhere on the track at speed."""
+        self.solver.set_x0(np.asarray(x0, dtype=np.float64).reshape(self.B, NX))
+        self.solver.init_guess(v_ref_scale)
 
     def compute_control_device(self):
         """Zero-copy step for closed loops whose state already lives on the device (``sim_advance``)."""

@@ -1,0 +1,85 @@
+"""Measures the BASELINE.json configurations that fit one GPU (beyond the bench.py headline run).
+
+    python tools/measure_configs.py            # on the GPU box; prints one JSON line per configuration
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from ihm2_amd import ocp as O  # noqa: E402
+from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop  # noqa: E402
+from ihm2_amd.controller import IHM2Controller  # noqa: E402
+from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
+from ihm2_amd.track import track_table  # noqa: E402
+
+
+def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference"):
+    plans = [track_table(t) for t in tracks]
+    mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, O.fkin6_model if model == "fkin6" else O.fdyn6_model, 8, 2, 3000)
+    ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
+    ocp.cost.W, ocp.cost.W_e = O.default_weights()
+    ocp.solver_options.tf = 2.0
+    if terminal_bounds == "stage":      # see IHM2Controller(terminal_bounds=...): quirk Q1
+        c = ocp.constraints
+        c.idxbx_e, c.lbx_e, c.ubx_e = c.idxbx.copy(), c.lbx.copy(), c.ubx.copy()
+    s_ref = np.stack([p.s_ref for p in plans]); k_ref = np.stack([p.kappa_ref for p in plans])
+    tid = (np.arange(B) % len(plans)).astype(np.int32)
+    solver = BatchedOcpSolver(ocp, B, s_ref, k_ref, track_id=tid)
+    x0 = np.zeros((B, 8))
+    for t, p in enumerate(plans):
+        sel = tid == t
+        x0[sel] = bench.sample_x0(p, int(sel.sum()), seed=20240607 + t)
+    solver.set_x0(x0); solver.init_guess()
+    if model == "fdyn6":          # a few SQP iterations on the frozen problem: the kinematic rollout is not a dynamic trajectory
+        yref = np.zeros((B, 40, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(40)[None] / 40
+        yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+        solver.set_yref(yref); solver.set_yref_e(yref_e); solver.solve(3)
+    plant = 0 if model == "fkin6" else 1
+
+    def step():
+        solver.sim_advance(model=plant, M_sim=25); solver.prepare_step(40.0); solver.solve_async(); return solver.get_u0()
+
+    for _ in range(warmup):
+        step()
+    solver.synchronize(); t0 = time.perf_counter(); tl = tq = 0.0
+    for _ in range(steps):
+        step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]
+    solver.synchronize(); el = time.perf_counter() - t0
+    st = solver.get_status()
+    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+               qp_ms=tq / steps, status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
+               qp_iter_mean=float(solver.get_qp_iter().mean()))
+    solver.free()
+    return out
+
+
+def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference"):
+    plan = track_table("fsds_competition_1")
+    ctrl = IHM2Controller(plan.s_ref, plan.kappa_ref, batch_size=B, terminal_bounds=terminal_bounds)
+    sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=100), SimModelVariant.KIN6_DYN6)
+    x0 = bench.sample_x0(plan, B, seed=5)
+    ctrl.warm_start(x0)
+    t0 = time.perf_counter()
+    res = run_closed_loop(ctrl, sim, x0, steps, lap_length=plan.lap_length)
+    el = time.perf_counter() - t0
+    st = res.stats()
+    return dict(config=5, terminal_bounds=terminal_bounds, B=B, steps=int(res.u.shape[0]), wall_s=el, control_steps_per_s=B * res.u.shape[0] / el, alive=int(res.alive.sum()),
+                finished=int(res.finished.sum()), failed=st["failed"], mean_speed=st["mean_speed"],
+                progress_m_median=float(np.median(res.x[-1, :, 0] - res.x[0, :, 0])))
+
+
+if __name__ == "__main__":
+    all_tracks = ("fsds_competition_1", "fsds_competition_2", "fsds_competition_3", "fsds_default")
+    for fn, kw in ((rti_throughput, dict(model="fkin6", B=1024)), (rti_throughput, dict(model="fkin6", B=8192)),
+                   (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage")),
+                   (rti_throughput, dict(model="fdyn6", B=8192, tracks=all_tracks, terminal_bounds="stage")),
+                   (closed_loop_config5, dict(B=4096, steps=200)),
+                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage"))):
+        print(json.dumps(fn(**kw)), flush=True)
