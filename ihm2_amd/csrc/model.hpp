@@ -95,16 +95,18 @@ __device__ __forceinline__ void fkin6_eval(const double (&x)[8], double u_T, dou
     const double poly = k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x;
     const double F_drag = -poly * sg;
     const double F_Rx = 0.5 * F_motor + F_drag, F_Fx = 0.5 * F_motor;
-    // slip angle of the kinematic model (models.py:261-284)
-    const double td = tan(delta);
-    const double beta = atan(c * td);
-    double sb, cb;
-    sincos(beta, &sb, &cb);
+    // slip angle of the kinematic model (models.py:261-284): beta = atan(c tan(delta)).  One sincos(delta) and
+    // one rsqrt replace tan, atan, sincos(beta) and sincos(delta - beta):
+    //   cos(beta) = cd / sqrt(cd^2 + c^2 sd^2), sin(beta) = c sd / sqrt(cd^2 + c^2 sd^2)   (cd > 0 for |delta| < pi/2)
+    double sd, cd;
+    sincos(delta, &sd, &cd);
+    const double td = sd / cd;
+    const double hyp = 1.0 / sqrt(cd * cd + c * c * sd * sd);
+    const double cb = cd * hyp, sb = c * sd * hyp;
     const double den = 1.0 + c * c * td * td;
     const double bp = c * (1.0 + td * td) / den;          // d beta / d delta
     const double beta_dot = bp * delta_dot;
-    double sdb, cdb;
-    sincos(delta - beta, &sdb, &cdb);
+    const double cdb = cd * cb + sd * sb, sdb = sd * cb - cd * sb;      // cos / sin (delta - beta)
     const double v_dot = (F_Rx * cb + F_Fx * cdb) * (1.0 / k_m);
     // Frenet kinematics (models.py:290-301)
     double dk;
