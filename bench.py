@@ -119,7 +119,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("IHM2_FORCE_DIST") == "1":      # the latter: rehearse the RCCL path on one GPU
         import torch
         import torch.distributed as dist
 

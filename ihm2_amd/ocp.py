@@ -105,6 +105,15 @@ class AcadosOcpCost:
     Vx_e: np.ndarray = field(default_factory=lambda: np.eye(NX))
     yref: np.ndarray = field(default_factory=lambda: np.ones(NY))
     yref_e: np.ndarray = field(default_factory=lambda: np.ones(NX))
+    # slack penalties, one entry per soft constraint in the order [sbx..., sg...] (acados: zl s + 1/2 Zl s^2 ...)
+    zl: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    zu: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    Zl: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    Zu: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    zl_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    zu_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    Zl_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    Zu_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
 
 
 @dataclass
@@ -123,6 +132,10 @@ class AcadosOcpConstraints:
     D: np.ndarray = field(default_factory=lambda: np.zeros((NG, NU)))
     lg: np.ndarray = field(default_factory=lambda: np.full(NG, -INF))
     ug: np.ndarray = field(default_factory=lambda: np.full(NG, INF))
+    # soft constraints (acados names; old/generate_acaods_interface.py:380-449): positions within idxbx / the rows of C
+    idxsbx: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    idxsbx_e: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    idxsg: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
 
 
 @dataclass
@@ -248,6 +261,8 @@ class OcpData:
     nlp_solver_type: str = "SQP_RTI"
     nlp_solver_max_iter: int = 1
     nlp_tol: float = 1e-6
+    soft_z: np.ndarray | None = None   # (N+1,24) linear slack penalty per one-sided constraint (12 lower, 12 upper)
+    soft_Z: np.ndarray | None = None   # (N+1,24) quadratic slack penalty; < 0 = hard side
 
     @staticmethod
     def from_ocp(ocp: AcadosOcp) -> "OcpData":
@@ -286,7 +301,30 @@ class OcpData:
             raise ValueError(f"at most {NG} general constraint rows")
         Cm = np.zeros((NG, NX)); Dm = np.zeros((NG, NU)); lg = np.full(NG, -INF); ug = np.full(NG, INF)
         Cm[:ng] = c.C; Dm[:ng] = c.D; lg[:ng] = c.lg; ug[:ng] = c.ug
+        # soft sides: slot rows 0..7 state boxes, 8..9 input boxes, 10..11 general rows
+        soft_z = soft_Z = None
+        cost = ocp.cost
+        nsbx, nsg, nsbx_e = len(c.idxsbx), len(c.idxsg), len(c.idxsbx_e)
+        if nsbx + nsg + nsbx_e > 0:
+            soft_z = np.zeros((N + 1, 24)); soft_Z = np.full((N + 1, 24), -1.0)
+            if len(cost.zl) != nsbx + nsg or len(cost.Zl) != nsbx + nsg or len(cost.zu) != nsbx + nsg or len(cost.Zu) != nsbx + nsg:
+                raise ValueError("cost.zl/zu/Zl/Zu need one entry per soft constraint [sbx..., sg...]")
+            if len(cost.zl_e) != nsbx_e or len(cost.Zl_e) != nsbx_e or len(cost.zu_e) != nsbx_e or len(cost.Zu_e) != nsbx_e:
+                raise ValueError("cost.zl_e/zu_e/Zl_e/Zu_e need one entry per terminal soft bound")
+            for j, pos in enumerate(np.asarray(c.idxsbx, dtype=int)):
+                row = int(idx[pos])
+                soft_z[1:N, row], soft_Z[1:N, row] = cost.zl[j], cost.Zl[j]
+                soft_z[1:N, 12 + row], soft_Z[1:N, 12 + row] = cost.zu[j], cost.Zu[j]
+            for j, pos in enumerate(np.asarray(c.idxsg, dtype=int)):
+                row = 10 + int(pos)
+                soft_z[:N, row], soft_Z[:N, row] = cost.zl[nsbx + j], cost.Zl[nsbx + j]
+                soft_z[:N, 12 + row], soft_Z[:N, 12 + row] = cost.zu[nsbx + j], cost.Zu[nsbx + j]
+            for j, pos in enumerate(np.asarray(c.idxsbx_e, dtype=int)):
+                row = int(idxe[pos])
+                soft_z[N, row], soft_Z[N, row] = cost.zl_e[j], cost.Zl_e[j]
+                soft_z[N, 12 + row], soft_Z[N, 12 + row] = cost.zu_e[j], cost.Zu_e[j]
         return OcpData(
+            soft_z=soft_z, soft_Z=soft_Z,
             N=N, M=int(o.sim_method_num_steps), dt=dt, model=ocp.model.model_id,
             integrator=INTEG_RK4,
             cost_scale_stage=dt if o.cost_scale_stage is None else float(o.cost_scale_stage),
@@ -304,6 +342,7 @@ class OcpData:
         d = {k: getattr(self, k) for k in (
             "N", "M", "dt", "model", "integrator", "cost_scale_stage", "W", "W_e", "lbx", "ubx", "lbu", "ubu",
             "C", "D", "lg", "ug", "ipm_iter_max", "ipm_tol", "ipm_mu0", "ipm_tau0")}
+        d["soft_z"], d["soft_Z"] = self.soft_z, self.soft_Z
         d["s_ref"] = np.atleast_2d(np.asarray(s_ref, dtype=float))
         d["kappa_ref"] = np.atleast_2d(np.asarray(kappa_ref, dtype=float))
         return d

@@ -62,6 +62,10 @@ typedef struct {
     const double *D;   /* (N, 2, 2) */
     const double *lg;  /* (N, 2) */
     const double *ug;  /* (N, 2) */
+    /* soft constraint sides (old/generate_acaods_interface.py:380-395): (N+1,24) per one-sided constraint,
+     * 12 lower then 12 upper; soft_Z < 0 = hard; NULL = all hard */
+    const double *soft_z;
+    const double *soft_Z;
     /* interior-point options */
     int ipm_iter_max;
     double ipm_tol;  /* abs inf-norm tolerance on all four residual groups */
@@ -98,6 +102,14 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
                  const double *b, const double *dx0, const double *R, const double *dl,
                  const double *du, int iter_max, double tol, double mu0, double tau0, double *dz,
                  double *pi, double *lam, double *t, double *stats, int *iters);
+
+/* same with SOFT constraint sides: soft_z, soft_Z (N+1,24) per one-sided constraint (12 lower then 12 upper);
+ * a side with soft_Z >= 0 carries a slack s >= 0 with cost soft_z s + 1/2 soft_Z s^2; sl (N+1,24): slack values out */
+int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, const double *Bm,
+                      const double *b, const double *dx0, const double *R, const double *dl,
+                      const double *du, const double *soft_z, const double *soft_Z, int iter_max, double tol,
+                      double mu0, double tau0, double *dz, double *pi, double *lam, double *t, double *sl,
+                      double *stats, int *iters);
 
 /* --- one SQP-RTI iteration for a batch (OpenMP over instances) ---
  * x (B,N+1,8), u (B,N,2), x0 (B,8), yref (B,N,12), yref_e (B,8), track_id (B)

@@ -154,23 +154,36 @@ static void riccati_forward(const qp_work *w, const double *rb, const double *p,
     }
 }
 
-int orc_qp_solve(int N, const double *H, const double *g, const double *A, const double *Bm,
-                 const double *b, const double *dx0, const double *R, const double *dl,
-                 const double *du, int iter_max, double tol, double mu0, double tau0, double *z,
-                 double *pi, double *lam, double *t, double *stats, int *iters)
+/* One-sided view of the constraints: index i = k*24 + c (c < 12: lower side, sigma = +1, bound dl) or
+ * k*24 + 12 + c (upper side, sigma = -1, bound du).  t_i = sigma (R z) [+ s_i] - sigma d_i >= 0.
+ * SOFT sides (soft_Z[i] >= 0; reference: old/generate_acaods_interface.py:380-395, zl/zu/Zl/Zu) carry a slack
+ * variable s_i >= 0 with cost soft_z[i] s_i + 1/2 soft_Z[i] s_i^2 and its own multiplier lam_s_i; the slack
+ * block is eliminated from the Newton system in closed form:
+ *   D = Z + lam/t + lam_s/s,  gamma_eff = (lam/t)(Z + lam_s/s)/D,  coef_eff = c1 - (lam/t)(rs + c1 + c2)/D,
+ *   ds = -(rs + c1 + c2)/D - (lam/t)/D * sigma R dz,  c1 = (rm1 + lam rd)/t, c2 = rm2/s, rs = Z s + z - lam - lam_s. */
+int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, const double *Bm,
+                      const double *b, const double *dx0, const double *R, const double *dl,
+                      const double *du, const double *soft_z, const double *soft_Z, int iter_max, double tol,
+                      double mu0, double tau0, double *z, double *pi, double *lam, double *t, double *sl,
+                      double *stats, int *iters)
 {
     static _Thread_local qp_work w;
     w.N = N; w.H = H; w.g = g; w.A = A; w.Bm = Bm; w.b = b; w.R = R; w.dl = dl; w.du = du;
-    const int NS = N + 1;
+    const int NS = N + 1, NI = NS * 2 * NC;
     double rg[(ORC_NMAX + 1) * NZ], rb[ORC_NMAX * NX], gt[(ORC_NMAX + 1) * NZ];
     double p[(ORC_NMAX + 1) * NX], kff[ORC_NMAX * NU];
     double dz[(ORC_NMAX + 1) * NZ], dpi[(ORC_NMAX + 1) * NX];
     double Rz[(ORC_NMAX + 1) * NC];
-    double rd[(ORC_NMAX + 1) * 2 * NC], rm[(ORC_NMAX + 1) * 2 * NC];
+    double rd[(ORC_NMAX + 1) * 2 * NC], rm[(ORC_NMAX + 1) * 2 * NC], bnd[(ORC_NMAX + 1) * 2 * NC];
     double dlam[(ORC_NMAX + 1) * 2 * NC], dt[(ORC_NMAX + 1) * 2 * NC];
     double dlam_a[(ORC_NMAX + 1) * 2 * NC], dt_a[(ORC_NMAX + 1) * 2 * NC];
-    unsigned char act[(ORC_NMAX + 1) * 2 * NC];
+    /* slack block of the soft sides */
+    double s[(ORC_NMAX + 1) * 2 * NC], lams[(ORC_NMAX + 1) * 2 * NC], rs[(ORC_NMAX + 1) * 2 * NC], rm2[(ORC_NMAX + 1) * 2 * NC];
+    double ds[(ORC_NMAX + 1) * 2 * NC], dlams[(ORC_NMAX + 1) * 2 * NC], ds_a[(ORC_NMAX + 1) * 2 * NC], dlams_a[(ORC_NMAX + 1) * 2 * NC];
+    unsigned char act[(ORC_NMAX + 1) * 2 * NC], soft[(ORC_NMAX + 1) * 2 * NC];
     int status = 1, it = 0, m_act = 0;
+#define SGN(i) ((((i) % (2 * NC)) < NC) ? 1.0 : -1.0)
+#define ROW(i) (((i) / (2 * NC)) * NC + ((i) % NC))
 
     /* initial point: z = 0 except x_0 = dx0; pi = 0; slacks clamped from below */
     memset(z, 0, sizeof(double) * NS * NZ);
@@ -189,17 +202,35 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
         for (int c = 0; c < NC; c++) {
             double rz = 0;
             for (int j = 0; j < NZ; j++) rz += R[(k * NC + c) * NZ + j] * z[k * NZ + j];
-            int il = k * 2 * NC + c, iu = il + NC;
-            act[il] = (unsigned char)is_fin(dl[k * NC + c]);
-            act[iu] = (unsigned char)is_fin(du[k * NC + c]);
-            /* slack floor: tau0, but never more than a quarter of a two-sided constraint's width */
-            double tau_c = tau0;
-            if (act[il] && act[iu]) tau_c = fmin(tau0, 0.25 * (du[k * NC + c] - dl[k * NC + c]));
-            if (act[il]) { t[il] = fmax(rz - dl[k * NC + c], tau_c); lam[il] = mu0 / t[il]; m_act++; }
-            else { t[il] = 1.0; lam[il] = 0.0; }
-            if (act[iu]) { t[iu] = fmax(du[k * NC + c] - rz, tau_c); lam[iu] = mu0 / t[iu]; m_act++; }
-            else { t[iu] = 1.0; lam[iu] = 0.0; }
+            Rz[k * NC + c] = rz;
         }
+    for (int i = 0; i < NI; i++) {
+        const int k = i / (2 * NC), c = i % NC;
+        bnd[i] = (SGN(i) > 0) ? dl[k * NC + c] : du[k * NC + c];
+        act[i] = (unsigned char)is_fin(bnd[i]);
+        soft[i] = (unsigned char)(act[i] && soft_Z && soft_Z[i] >= 0.0);
+        s[i] = 0.0; lams[i] = 0.0; t[i] = 1.0; lam[i] = 0.0;
+        if (sl) sl[i] = 0.0;
+    }
+    for (int i = 0; i < NI; i++) {
+        if (!act[i]) continue;
+        const int k = i / (2 * NC), c = i % NC;
+        const double slack = SGN(i) * (Rz[ROW(i)] - bnd[i]);
+        if (soft[i]) {
+            s[i] = fmax(tau0, tau0 - slack);
+            t[i] = slack + s[i];
+            lams[i] = mu0 / s[i];
+            m_act++;
+        } else {
+            /* slack floor: tau0, but never more than a quarter of a two-sided hard constraint's width */
+            double tau_c = tau0;
+            const int other = (SGN(i) > 0) ? i + NC : i - NC;
+            if (act[other] && !soft[other]) tau_c = fmin(tau0, 0.25 * (du[k * NC + c] - dl[k * NC + c]));
+            t[i] = fmax(slack, tau_c);
+        }
+        lam[i] = mu0 / t[i];
+        m_act++;
+    }
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
     for (it = 0;; it++) {
         /* ---- residuals ---- */
@@ -235,13 +266,17 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
                     rb[k * NX + i] = acc;
                     res_b = fmax(res_b, fabs(acc));
                 }
-            for (int c = 0; c < NC; c++) {
-                int il = k * 2 * NC + c, iu = il + NC;
-                rd[il] = act[il] ? (Rz[k * NC + c] - t[il] - dl[k * NC + c]) : 0.0;
-                rd[iu] = act[iu] ? (du[k * NC + c] - Rz[k * NC + c] - t[iu]) : 0.0;
-                res_d = fmax(res_d, fmax(fabs(rd[il]), fabs(rd[iu])));
-                if (act[il]) { mu += lam[il] * t[il]; res_m = fmax(res_m, fabs(lam[il] * t[il])); }
-                if (act[iu]) { mu += lam[iu] * t[iu]; res_m = fmax(res_m, fabs(lam[iu] * t[iu])); }
+        }
+        for (int i = 0; i < NI; i++) {
+            rd[i] = 0.0; rs[i] = 0.0;
+            if (!act[i]) continue;
+            rd[i] = SGN(i) * (Rz[ROW(i)] - bnd[i]) + s[i] - t[i];
+            res_d = fmax(res_d, fabs(rd[i]));
+            mu += lam[i] * t[i]; res_m = fmax(res_m, fabs(lam[i] * t[i]));
+            if (soft[i]) {
+                rs[i] = soft_Z[i] * s[i] + soft_z[i] - lam[i] - lams[i];
+                res_g = fmax(res_g, fabs(rs[i]));
+                mu += lams[i] * s[i]; res_m = fmax(res_m, fabs(lams[i] * s[i]));
             }
         }
         if (m_act > 0) mu /= m_act;
@@ -251,38 +286,33 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
         if (it >= iter_max) { status = 1; break; }
 
         /* ---- barrier-augmented Hessian ---- */
-        for (int k = 0; k < NS; k++) {
-            memcpy(w.Ht[k], H + k * NZ * NZ, sizeof(double) * NZ * NZ);
-            for (int c = 0; c < NC; c++) {
-                int il = k * 2 * NC + c, iu = il + NC;
-                double gam = (act[il] ? lam[il] / t[il] : 0.0) + (act[iu] ? lam[iu] / t[iu] : 0.0);
-                if (gam == 0.0) continue;
-                const double *r = R + (k * NC + c) * NZ;
-                for (int i = 0; i < NZ; i++)
-                    for (int j = 0; j < NZ; j++) w.Ht[k][i * NZ + j] += gam * r[i] * r[j];
-            }
+        for (int k = 0; k < NS; k++) memcpy(w.Ht[k], H + k * NZ * NZ, sizeof(double) * NZ * NZ);
+        for (int i = 0; i < NI; i++) {
+            if (!act[i]) continue;
+            double gam = lam[i] / t[i];
+            if (soft[i]) { const double gs = lams[i] / s[i]; gam = gam * (soft_Z[i] + gs) / (soft_Z[i] + gam + gs); }
+            const int k = i / (2 * NC);
+            const double *r = R + ROW(i) * NZ;
+            for (int a2 = 0; a2 < NZ; a2++)
+                for (int j = 0; j < NZ; j++) w.Ht[k][a2 * NZ + j] += gam * r[a2] * r[j];
         }
         /* ---- predictor (sigma = 0), then corrector ---- */
         double alpha = 1.0, sigma = 0.0;
         for (int pass = 0; pass < 2; pass++) {
-            for (int k = 0; k < NS; k++) {
-                for (int j = 0; j < NZ; j++) gt[k * NZ + j] = rg[k * NZ + j];
-                for (int c = 0; c < NC; c++) {
-                    int il = k * 2 * NC + c, iu = il + NC;
-                    if (pass == 0) { rm[il] = lam[il] * t[il]; rm[iu] = lam[iu] * t[iu]; }
-                    else {
-                        double mu_target = fmax(sigma * mu, mu_floor); /* never aim below the tolerance */
-                        rm[il] = lam[il] * t[il] + dlam_a[il] * dt_a[il] - mu_target;
-                        rm[iu] = lam[iu] * t[iu] + dlam_a[iu] * dt_a[iu] - mu_target;
-                    }
-                    double coef = 0.0;
-                    if (act[il]) coef += (rm[il] + lam[il] * rd[il]) / t[il];
-                    if (act[iu]) coef -= (rm[iu] + lam[iu] * rd[iu]) / t[iu];
-                    if (coef != 0.0) {
-                        const double *r = R + (k * NC + c) * NZ;
-                        for (int j = 0; j < NZ; j++) gt[k * NZ + j] += coef * r[j];
-                    }
+            const double mu_target = fmax(sigma * mu, mu_floor); /* never aim below the tolerance */
+            memcpy(gt, rg, sizeof(double) * NS * NZ);
+            for (int i = 0; i < NI; i++) {
+                if (!act[i]) continue;
+                rm[i] = lam[i] * t[i]; rm2[i] = lams[i] * s[i];
+                if (pass == 1) { rm[i] += dlam_a[i] * dt_a[i] - mu_target; if (soft[i]) rm2[i] += dlams_a[i] * ds_a[i] - mu_target; }
+                double coef = (rm[i] + lam[i] * rd[i]) / t[i];
+                if (soft[i]) {
+                    const double gam = lam[i] / t[i], gs = lams[i] / s[i], D = soft_Z[i] + gam + gs;
+                    coef -= gam * (rs[i] + coef + rm2[i] / s[i]) / D;
                 }
+                const int k = i / (2 * NC);
+                const double *r = R + ROW(i) * NZ;
+                for (int j = 0; j < NZ; j++) gt[k * NZ + j] += SGN(i) * coef * r[j];
             }
             riccati_backward(&w, pass == 0, gt, rb, p, kff);
             riccati_forward(&w, rb, p, kff, dz, dpi);
@@ -292,29 +322,37 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
                 for (int c = 0; c < NC; c++) {
                     double drz = 0;
                     for (int j = 0; j < NZ; j++) drz += R[(k * NC + c) * NZ + j] * dz[k * NZ + j];
-                    int il = k * 2 * NC + c, iu = il + NC;
-                    if (act[il]) {
-                        dt[il] = drz + rd[il];
-                        dlam[il] = -(rm[il] + lam[il] * dt[il]) / t[il];
-                        if (dt[il] < 0) amax = fmin(amax, -t[il] / dt[il]);
-                        if (dlam[il] < 0) amax = fmin(amax, -lam[il] / dlam[il]);
-                    } else { dt[il] = 0; dlam[il] = 0; }
-                    if (act[iu]) {
-                        dt[iu] = -drz + rd[iu];
-                        dlam[iu] = -(rm[iu] + lam[iu] * dt[iu]) / t[iu];
-                        if (dt[iu] < 0) amax = fmin(amax, -t[iu] / dt[iu]);
-                        if (dlam[iu] < 0) amax = fmin(amax, -lam[iu] / dlam[iu]);
-                    } else { dt[iu] = 0; dlam[iu] = 0; }
+                    Rz[k * NC + c] = drz;   /* R dz */
                 }
+            for (int i = 0; i < NI; i++) {
+                dt[i] = dlam[i] = ds[i] = dlams[i] = 0.0;
+                if (!act[i]) continue;
+                const double y = SGN(i) * Rz[ROW(i)];
+                if (soft[i]) {
+                    const double gam = lam[i] / t[i], gs = lams[i] / s[i], D = soft_Z[i] + gam + gs;
+                    const double c1 = (rm[i] + lam[i] * rd[i]) / t[i], c2 = rm2[i] / s[i];
+                    ds[i] = -(rs[i] + c1 + c2) / D - gam / D * y;
+                    dlams[i] = -(rm2[i] + lams[i] * ds[i]) / s[i];
+                    if (ds[i] < 0) amax = fmin(amax, -s[i] / ds[i]);
+                    if (dlams[i] < 0) amax = fmin(amax, -lams[i] / dlams[i]);
+                }
+                dt[i] = y + ds[i] + rd[i];
+                dlam[i] = -(rm[i] + lam[i] * dt[i]) / t[i];
+                if (dt[i] < 0) amax = fmin(amax, -t[i] / dt[i]);
+                if (dlam[i] < 0) amax = fmin(amax, -lam[i] / dlam[i]);
+            }
             if (pass == 0) {
                 double mu_aff = 0;
-                for (int i = 0; i < NS * 2 * NC; i++)
-                    if (act[i]) mu_aff += (lam[i] + amax * dlam[i]) * (t[i] + amax * dt[i]);
+                for (int i = 0; i < NI; i++) {
+                    if (!act[i]) continue;
+                    mu_aff += (lam[i] + amax * dlam[i]) * (t[i] + amax * dt[i]);
+                    if (soft[i]) mu_aff += (lams[i] + amax * dlams[i]) * (s[i] + amax * ds[i]);
+                }
                 if (m_act > 0) mu_aff /= m_act;
                 double ratio = (mu > 0) ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
-                memcpy(dlam_a, dlam, sizeof(double) * NS * 2 * NC);
-                memcpy(dt_a, dt, sizeof(double) * NS * 2 * NC);
+                memcpy(dlam_a, dlam, sizeof(double) * NI); memcpy(dt_a, dt, sizeof(double) * NI);
+                memcpy(dlams_a, dlams, sizeof(double) * NI); memcpy(ds_a, ds, sizeof(double) * NI);
                 if (m_act == 0) { alpha = 1.0; break; } /* no inequalities: Newton step is exact */
             } else {
                 alpha = fmin(1.0, 0.995 * amax);
@@ -326,13 +364,27 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
             for (int j = 0; j < NZ; j++) z[k * NZ + j] += alpha * dz[k * NZ + j];
             for (int i = 0; i < NX; i++) pi[k * NX + i] += alpha * dpi[k * NX + i];
         }
-        for (int i = 0; i < NS * 2 * NC; i++)
-            if (act[i]) { lam[i] += alpha * dlam[i]; t[i] += alpha * dt[i]; }
+        for (int i = 0; i < NI; i++)
+            if (act[i]) {
+                lam[i] += alpha * dlam[i]; t[i] += alpha * dt[i];
+                if (soft[i]) { lams[i] += alpha * dlams[i]; s[i] += alpha * ds[i]; }
+            }
     }
+#undef SGN
+#undef ROW
     /* max-iter exits that are converged to the loose tolerance (1e4 x tol) are reported as status 1
        ("acceptable": acados RTI tolerates ACADOS_MAXITER from the QP); otherwise status 4 = failed */
     if (status == 1 && !(res_g <= 1e4 * tol_g && res_b <= 1e4 * tol_b && res_d <= 1e4 * tol_d && res_m <= 1e4 * tol_m)) status = 4;
+    if (sl) for (int i = 0; i < NI; i++) sl[i] = soft[i] ? s[i] : 0.0;
     if (stats) { stats[0] = res_g; stats[1] = res_b; stats[2] = res_d; stats[3] = res_m; stats[4] = mu; stats[5] = sg; stats[6] = sb; }
     if (iters) *iters = it;
     return status;
+}
+
+int orc_qp_solve(int N, const double *H, const double *g, const double *A, const double *Bm,
+                 const double *b, const double *dx0, const double *R, const double *dl,
+                 const double *du, int iter_max, double tol, double mu0, double tau0, double *z,
+                 double *pi, double *lam, double *t, double *stats, int *iters)
+{
+    return orc_qp_solve_soft(N, H, g, A, Bm, b, dx0, R, dl, du, 0, 0, iter_max, tol, mu0, tau0, z, pi, lam, t, 0, stats, iters);
 }

@@ -176,15 +176,17 @@ static void rti_one(const orc_problem *P, double *x, double *u, const double *x0
         if (k < N) for (int i = 0; i < NX; i++) r_eq = fmax(r_eq, fabs(b[k * NX + i]));
         for (int c = 0; c < NC; c++) {
             double ll = dl[k * NC + c], uu = du[k * NC + c]; /* = bound - c(z): slack is -ll, uu */
-            if (fabs(ll) < INF_BOUND) { r_ineq = fmax(r_ineq, ll); r_comp = fmax(r_comp, fabs(lam[k * 2 * NC + c] * ll)); }
-            if (fabs(uu) < INF_BOUND) { r_ineq = fmax(r_ineq, -uu); r_comp = fmax(r_comp, fabs(lam[k * 2 * NC + NC + c] * uu)); }
+            /* soft sides may be violated: they do not count as infeasibility */
+            const int sl_ = P->soft_Z && P->soft_Z[k * 2 * NC + c] >= 0.0, su_ = P->soft_Z && P->soft_Z[k * 2 * NC + NC + c] >= 0.0;
+            if (fabs(ll) < INF_BOUND && !sl_) { r_ineq = fmax(r_ineq, ll); r_comp = fmax(r_comp, fabs(lam[k * 2 * NC + c] * ll)); }
+            if (fabs(uu) < INF_BOUND && !su_) { r_ineq = fmax(r_ineq, -uu); r_comp = fmax(r_comp, fabs(lam[k * 2 * NC + NC + c] * uu)); }
         }
     }
     res[0] = r_stat; res[1] = r_eq; res[2] = r_ineq; res[3] = r_comp;
 
     int iters = 0;
-    int qs = orc_qp_solve(N, H, g, A, Bm, b, dx0, R, dl, du, P->ipm_iter_max, P->ipm_tol, P->ipm_mu0,
-                          P->ipm_tau0, dz, qpi, qlam, qt, stats, &iters);
+    int qs = orc_qp_solve_soft(N, H, g, A, Bm, b, dx0, R, dl, du, P->soft_z, P->soft_Z, P->ipm_iter_max, P->ipm_tol,
+                               P->ipm_mu0, P->ipm_tau0, dz, qpi, qlam, qt, 0, stats, &iters);
     *qp_iter = iters;
     int st = 0;
     if (qs == 3) st = 1;                 /* NaN */

@@ -27,7 +27,7 @@ class _Problem(C.Structure):
         ("dt", C.c_double), ("cost_scale_stage", C.c_double),
         ("ntracks", C.c_int), ("nknots", C.c_int), ("s_ref", _dp), ("kappa_ref", _dp),
         ("W", _dp), ("W_e", _dp), ("lbx", _dp), ("ubx", _dp), ("lbu", _dp), ("ubu", _dp),
-        ("C", _dp), ("D", _dp), ("lg", _dp), ("ug", _dp),
+        ("C", _dp), ("D", _dp), ("lg", _dp), ("ug", _dp), ("soft_z", _dp), ("soft_Z", _dp),
         ("ipm_iter_max", C.c_int), ("ipm_tol", C.c_double), ("ipm_mu0", C.c_double), ("ipm_tau0", C.c_double),
     ]
 
@@ -100,16 +100,24 @@ def rk4(model, x, u, s_ref, kappa_ref, dt, M, integrator=INTEG_RK4):
     return xn
 
 
-def qp_solve(H, g, A, Bm, b, dx0, R, dl, du, iter_max=50, tol=1e-6, mu0=0.03, tau0=0.1):
+def qp_solve(H, g, A, Bm, b, dx0, R, dl, du, iter_max=50, tol=1e-6, mu0=0.03, tau0=0.1, soft_z=None, soft_Z=None):
     N = A.shape[0]
     H, Hp = _d(H); g, gp = _d(g); A, Ap = _d(A); Bm, Bp = _d(Bm); b, bp = _d(b); dx0, xp = _d(dx0)
     R, Rp = _d(R); dl, lp = _d(dl); du, up = _d(du)
     dz = np.zeros((N + 1, NZ)); pi = np.zeros((N + 1, NX)); lam = np.zeros((N + 1, 2 * NC)); t = np.zeros((N + 1, 2 * NC))
+    sl = np.zeros((N + 1, 2 * NC))
     stats = np.zeros(8); iters = C.c_int(0)
-    st = lib().orc_qp_solve(C.c_int(N), Hp, gp, Ap, Bp, bp, xp, Rp, lp, up, C.c_int(iter_max), C.c_double(tol),
-                            C.c_double(mu0), C.c_double(tau0), dz.ctypes.data_as(_dp), pi.ctypes.data_as(_dp),
-                            lam.ctypes.data_as(_dp), t.ctypes.data_as(_dp), stats.ctypes.data_as(_dp), C.byref(iters))
-    return dict(status=st, dz=dz, pi=pi, lam=lam, t=t, stats=stats, iters=iters.value)
+    if soft_Z is None:
+        szp = sZp = None
+    else:
+        sz, szp = _d(soft_z); sZ, sZp = _d(soft_Z)
+        assert sz.shape == (N + 1, 2 * NC) and sZ.shape == (N + 1, 2 * NC)
+    fn = lib().orc_qp_solve_soft
+    fn.restype = C.c_int
+    st = fn(C.c_int(N), Hp, gp, Ap, Bp, bp, xp, Rp, lp, up, szp, sZp, C.c_int(iter_max), C.c_double(tol),
+            C.c_double(mu0), C.c_double(tau0), dz.ctypes.data_as(_dp), pi.ctypes.data_as(_dp),
+            lam.ctypes.data_as(_dp), t.ctypes.data_as(_dp), sl.ctypes.data_as(_dp), stats.ctypes.data_as(_dp), C.byref(iters))
+    return dict(status=st, dz=dz, pi=pi, lam=lam, t=t, sl=sl, stats=stats, iters=iters.value)
 
 
 class OracleProblem:
@@ -131,6 +139,12 @@ class OracleProblem:
             a, ptr = _d(arr)
             self._keep[name] = a
             setattr(p, name, ptr)
+        if desc.get("soft_Z") is not None:
+            for name in ("soft_z", "soft_Z"):
+                a, ptr = _d(desc[name])
+                assert a.shape == (self.N + 1, 2 * NC)
+                self._keep[name] = a
+                setattr(p, name, ptr)
         N = self.N
         assert self._keep["W"].shape == (N, NY, NY) and self._keep["lbx"].shape == (N + 1, NX)
         assert self._keep["C"].shape == (N, NG, NX) and self._keep["D"].shape == (N, NG, NU)

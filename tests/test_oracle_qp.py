@@ -148,3 +148,66 @@ def test_infeasible_qp_is_reported_not_nan():
     sol = orc.qp_solve(**qp, tol=1e-6, iter_max=40)
     assert sol["status"] in (2, 4)
     assert np.all(np.isfinite(sol["dz"]))
+
+
+def test_soft_constraints_match_explicit_slack_formulation():
+    """A QP whose hard version is infeasible: softened sides (L1 + L2 slack penalty, as
+    old/generate_acaods_interface.py:380-395) against SLSQP with explicit slack variables."""
+    N = 3
+    rng = np.random.default_rng(21)
+    qp = random_qp(rng, N)
+    # make the state box of stage 2 impossible to meet, then soften exactly those sides
+    k, c = 2, 1
+    qp["R"][k, c] = 0; qp["R"][k, c, c] = 1.0
+    zf = np.zeros((N + 1, NZ)); zf[0, :NX] = qp["dx0"]
+    for kk in range(N):
+        zf[kk + 1, :NX] = qp["A"][kk] @ zf[kk, :NX] + qp["b"][kk]
+    qp["dl"][k, c], qp["du"][k, c] = zf[k, c] + 30.0, zf[k, c] + 31.0      # unreachable with |u| <= 1
+    for kk in range(N):
+        qp["dl"][kk, 10], qp["du"][kk, 10] = -np.inf, np.inf                   # keep the test about the softened box
+    hard = orc.qp_solve(**qp, tol=1e-8, iter_max=60)
+    assert hard["status"] in (2, 4)
+    soft_z = np.zeros((N + 1, 2 * NC)); soft_Z = np.full((N + 1, 2 * NC), -1.0)
+    for side in (c, NC + c):
+        soft_z[k, side], soft_Z[k, side] = 100.0, 100.0
+    sol = orc.qp_solve(**qp, tol=1e-8, iter_max=80, soft_z=soft_z, soft_Z=soft_Z)
+    assert sol["status"] == 0
+    assert sol["sl"][k, c] > 1.0 and sol["sl"][k, NC + c] < 1e-6           # only the lower side is violated
+    assert np.all(sol["sl"] >= 0)
+
+    def rollout(uv):
+        u = uv.reshape(N, NU); z = np.zeros((N + 1, NZ)); z[0, :NX] = qp["dx0"]
+        for kk in range(N):
+            z[kk, NX:] = u[kk]
+            z[kk + 1, :NX] = qp["A"][kk] @ z[kk, :NX] + qp["Bm"][kk] @ u[kk] + qp["b"][kk]
+        return z
+
+    def obj(v):
+        z = rollout(v[:-2]); sl_, su_ = v[-2], v[-1]
+        return (sum(0.5 * z[kk] @ qp["H"][kk] @ z[kk] + qp["g"][kk] @ z[kk] for kk in range(N + 1))
+                + 100.0 * (sl_ + su_) + 50.0 * (sl_ ** 2 + su_ ** 2))
+
+    cons = [{"type": "ineq", "fun": lambda v: v[-2]}, {"type": "ineq", "fun": lambda v: v[-1]}]
+    for kk in range(N + 1):
+        for cc in range(NC):
+            if np.isfinite(qp["dl"][kk, cc]):
+                extra = (lambda v: v[-2]) if (kk, cc) == (k, c) else (lambda v: 0.0)
+                cons.append({"type": "ineq", "fun": lambda v, kk=kk, cc=cc, extra=extra: qp["R"][kk, cc] @ rollout(v[:-2])[kk] + extra(v) - qp["dl"][kk, cc]})
+            if np.isfinite(qp["du"][kk, cc]):
+                extra = (lambda v: v[-1]) if (kk, cc) == (k, c) else (lambda v: 0.0)
+                cons.append({"type": "ineq", "fun": lambda v, kk=kk, cc=cc, extra=extra: qp["du"][kk, cc] - qp["R"][kk, cc] @ rollout(v[:-2])[kk] + extra(v)})
+    # KKT of the slack block: Z s + z - lam - lam_s = 0, lam_s >= 0, lam_s s = 0
+    lam_soft = sol["lam"][k, c]
+    assert sol["sl"][k, c] > 0 and lam_soft == pytest.approx(100.0 * sol["sl"][k, c] + 100.0, rel=1e-6)
+    assert sol["lam"][k, NC + c] <= 100.0 + 1e-6                              # inactive side: lam <= z
+    stat, eq, ineq, comp, lam_min = kkt_report(dict(qp, dl=np.where(soft_Z[:, :NC] >= 0, -np.inf, qp["dl"]),
+                                                    du=np.where(soft_Z[:, NC:] >= 0, np.inf, qp["du"])), sol)
+    sg = max(1.0, np.abs(qp["g"]).max())
+    assert stat < 1e-7 * sg and eq < 1e-7 and ineq < 1e-7 and lam_min >= 0
+    # the violated constraint holds with its slack: R z + s >= dl
+    assert qp["R"][k, c] @ sol["dz"][k] + sol["sl"][k, c] >= qp["dl"][k, c] - 1e-7
+    # SLSQP started at the IPM point cannot improve the explicit-slack objective
+    v_ipm = np.concatenate([sol["dz"][:N, NX:].ravel(), [sol["sl"][k, c], sol["sl"][k, NC + c]]])
+    ref = minimize(obj, v_ipm, constraints=cons, method="SLSQP", options={"ftol": 1e-14, "maxiter": 200})
+    assert ref.fun >= obj(v_ipm) - 1e-6 * (1 + abs(obj(v_ipm)))
+    np.testing.assert_allclose(ref.x, v_ipm, rtol=1e-3, atol=1e-3)
