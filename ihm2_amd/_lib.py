@@ -40,6 +40,7 @@ SYMBOLS = {
     "ihm2mpc_set_track_id": (C.c_int, [_H, c_int32_p]),
     "ihm2mpc_set_weights": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_set_bounds": (C.c_int, [_H] + [c_double_p] * 8),
+    "ihm2mpc_set_soft": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_set_x0": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_x": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_u": (C.c_int, [_H, c_double_p]),
@@ -60,6 +61,7 @@ SYMBOLS = {
     "ihm2mpc_get_qp_iter": (C.c_int, [_H, c_int32_p]),
     "ihm2mpc_get_residuals": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_multipliers": (C.c_int, [_H, c_double_p, c_double_p]),
+    "ihm2mpc_get_slacks": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_timings": (C.c_int, [_H, c_double_p, C.c_int32]),
     "ihm2mpc_set_x0_device": (C.c_int, [_H, C.c_void_p]),
     "ihm2mpc_get_u0_device": (C.c_int, [_H, C.c_void_p]),

@@ -142,7 +142,11 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(track_id, B);
     DA(Hs, NS * 100); DA(Gy, NS * 120); DA(lbx, NS * 8); DA(ubx, NS * 8); DA(lbu, N * 2); DA(ubu, N * 2);
     DA(CD, N * 20); DA(lg, N * 2); DA(ug, N * 2);
-    DA(slot_kc, NS * 12); DA(slot_lb, NS * 12); DA(slot_ub, NS * 12);
+    DA(slot_kc, MAX_SLOTS); DA(slot_lb, MAX_SLOTS); DA(slot_ub, MAX_SLOTS); DA(slot_zw, MAX_SLOTS); DA(slot_Zw, MAX_SLOTS);
+    DA(slk, B * NS * 24);
+    h->host_lb = new double[NS * 12]; h->host_ub = new double[NS * 12];
+    h->host_sz = new double[NS * 24]; h->host_sZ = new double[NS * 24];
+    for (size_t i = 0; i < NS * 24; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
     DA(pi, B * NS * 8); DA(lam, B * NS * 24); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(u0, B * 2);
     DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, B * N * 64); DA(q_Mt, B * N * 64); DA(scratch, B * 24);
@@ -157,9 +161,10 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
                     h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->q_Mt, h->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -249,6 +254,70 @@ int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e)
     return 0;
 }
 
+// Constraint-slot table of the QP kernel.  A slot is a (stage, row) pair with its finite sides; a row with a SOFT
+// side is split into one-sided slots (the slack belongs to one side).  Lane `l` of the instance's wavefront owns the
+// entries l, l+64, ...; both halves of a split row go to the same lane (they accumulate into the same LDS words
+// without atomics) and a lane's soft slots come first (the kernel keeps slack registers for the first NSOFT only).
+static int rebuild_slots(ihm2mpc_handle *h)
+{
+    const int NS = h->NS;
+    struct Slot { int kc; double lb, ub, zw, Zw; };
+    std::vector<Slot> lanes[64];
+    int nsoft[64] = {0};
+    int m_act = 0, total = 0;
+    // two passes: rows with a soft side first, spread by soft count, then the hard rows by total count
+    for (int pass = 0; pass < 2; pass++)
+        for (int k = 0; k < NS; k++)
+            for (int c = 0; c < NC; c++) {
+                const double lb = h->host_lb[k * 12 + c], ub = h->host_ub[k * 12 + c];
+                const bool fl = std::isfinite(lb), fu = std::isfinite(ub);
+                if (!fl && !fu) continue;
+                const bool sl = fl && h->host_sZ[k * 24 + c] >= 0.0, su = fu && h->host_sZ[k * 24 + 12 + c] >= 0.0;
+                if ((sl || su) != (pass == 0)) continue;
+                int best = 0;       // least-loaded lane; ties -> lowest lane (round-robin for an all-hard table)
+                for (int l = 1; l < 64; l++) {
+                    const bool fewer_soft = nsoft[l] < nsoft[best], same_soft = nsoft[l] == nsoft[best];
+                    const bool fewer = lanes[l].size() < lanes[best].size();
+                    if (pass == 0 ? (fewer_soft || (same_soft && fewer)) : fewer) best = l;
+                }
+                std::vector<Slot> &L = lanes[best];
+                if (!sl && !su) L.push_back({k * 12 + c, lb, ub, 0.0, -1.0});
+                else {
+                    if (fl) L.push_back({k * 12 + c, lb, INFINITY, sl ? h->host_sz[k * 24 + c] : 0.0, sl ? h->host_sZ[k * 24 + c] : -1.0});
+                    if (fu) L.push_back({k * 12 + c, -INFINITY, ub, su ? h->host_sz[k * 24 + 12 + c] : 0.0, su ? h->host_sZ[k * 24 + 12 + c] : -1.0});
+                }
+                nsoft[best] += (int)sl + (int)su;
+                m_act += (int)fl + (int)fu + (int)sl + (int)su;
+            }
+    int per_lane = 0, soft_lane = 0;
+    for (int l = 0; l < 64; l++) {
+        std::stable_partition(lanes[l].begin(), lanes[l].end(), [](const Slot &s) { return s.Zw >= 0.0; });
+        per_lane = std::max(per_lane, (int)lanes[l].size());
+        soft_lane = std::max(soft_lane, nsoft[l]);
+        total += (int)lanes[l].size();
+    }
+    if (per_lane * 64 > MAX_SLOTS || soft_lane > 4)
+        return fail("%d constraint slots per lane (%d soft) exceed the QP kernel limits (10 per lane, 4 soft)", per_lane, soft_lane);
+    const size_t n = (size_t)per_lane * 64;
+    std::vector<int32_t> kc(n, -1);
+    std::vector<double> slb(n, -INFINITY), sub(n, INFINITY), zw(n, 0.0), Zw(n, -1.0);
+    for (int l = 0; l < 64; l++)
+        for (size_t r = 0; r < lanes[l].size(); r++) {
+            const Slot &s = lanes[l][r];
+            const size_t e = l + 64 * r;
+            kc[e] = s.kc; slb[e] = s.lb; sub[e] = s.ub; zw[e] = s.zw; Zw[e] = s.Zw;
+        }
+    h->nslots = total; h->m_act = m_act; h->nslot_lane = per_lane; h->nsoft_lane = soft_lane;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(h->slot_kc, kc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (upload_shared(h, slb.data(), h->slot_lb, n) || upload_shared(h, sub.data(), h->slot_ub, n) ||
+            upload_shared(h, zw.data(), h->slot_zw, n) || upload_shared(h, Zw.data(), h->slot_Zw, n))
+            return -1;
+    }
+    return 0;
+}
+
 int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, const double *lbu, const double *ubu,
                        const double *C, const double *D, const double *lg, const double *ug)
 {
@@ -264,34 +333,38 @@ int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, 
             for (int j = 0; j < NX; j++) CD[((size_t)k * 2 + r) * 10 + j] = C[((size_t)k * 2 + r) * NX + j];
             for (int j = 0; j < NU; j++) CD[((size_t)k * 2 + r) * 10 + 8 + j] = D[((size_t)k * 2 + r) * NU + j];
         }
-    // compact table of the constraint slots (stage, row) that have at least one finite side
-    std::vector<int32_t> kc; std::vector<double> slb, sub;
-    int m_act = 0;
     for (int k = 0; k < NS; k++)
         for (int c = 0; c < NC; c++) {
             double lb = -INFINITY, ub = INFINITY;
             if (c < 8) { if (k >= 1) { lb = lbx[k * 8 + c]; ub = ubx[k * 8 + c]; } }
             else if (c < 10) { if (k < N) { lb = lbu[k * 2 + c - 8]; ub = ubu[k * 2 + c - 8]; } }
             else { if (k < N) { lb = lg[k * 2 + c - 10]; ub = ug[k * 2 + c - 10]; } }
-            const bool fl = std::fabs(lb) < 1e20, fu = std::fabs(ub) < 1e20;
-            if (!fl && !fu) continue;
-            kc.push_back(k * 12 + c); slb.push_back(fl ? lb : -INFINITY); sub.push_back(fu ? ub : INFINITY);
-            m_act += (int)fl + (int)fu;
+            h->host_lb[k * 12 + c] = (std::fabs(lb) < 1e20) ? lb : -INFINITY;
+            h->host_ub[k * 12 + c] = (std::fabs(ub) < 1e20) ? ub : INFINITY;
         }
-    if (kc.size() > 8 * 64) return fail("%zu constraint slots exceed the kernel limit of 512 (8 per lane)", kc.size());
-    h->nslots = (int)kc.size();
-    h->m_act = m_act;
-    if (!kc.empty()) {
-        HIP_TRY(hipMemcpyAsync(h->slot_kc, kc.data(), kc.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (upload_shared(h, slb.data(), h->slot_lb, slb.size()) || upload_shared(h, sub.data(), h->slot_ub, sub.size())) return -1;
-    }
+    if (rebuild_slots(h)) return -1;
     if (upload_shared(h, lbx, h->lbx, (size_t)NS * 8) || upload_shared(h, ubx, h->ubx, (size_t)NS * 8) ||
         upload_shared(h, lbu, h->lbu, (size_t)N * 2) || upload_shared(h, ubu, h->ubu, (size_t)N * 2) ||
         upload_shared(h, CD.data(), h->CD, CD.size()) || upload_shared(h, lg, h->lg, (size_t)N * 2) ||
         upload_shared(h, ug, h->ug, (size_t)N * 2))
         return -1;
     h->bounds_set = true;
+    return 0;
+}
+
+int ihm2mpc_set_soft(ihm2mpc_handle *h, const double *soft_z, const double *soft_Z)
+{
+    CHECK_H(h);
+    const int n = h->NS * 24;
+    if ((soft_z == nullptr) != (soft_Z == nullptr)) return fail("soft_z and soft_Z must both be given or both be NULL");
+    for (int i = 0; i < n; i++) {
+        const double Z = soft_Z ? soft_Z[i] : -1.0, z = soft_z ? soft_z[i] : 0.0;
+        if (Z >= 0.0 && !(z >= 0.0)) return fail("soft_z < 0 at flat index %d (the slack penalty must be non-decreasing)", i);
+        if (Z >= 0.0 && !(Z + z > 0.0)) return fail("soft side %d has neither a linear nor a quadratic penalty", i);
+        h->host_sz[i] = z; h->host_sZ[i] = Z;
+    }
+    HIP_TRY(hipMemsetAsync(h->slk, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
+    if (h->bounds_set && rebuild_slots(h)) return -1;
     return 0;
 }
 
@@ -435,6 +508,7 @@ GETTER(u, u, h->N * NU)
 GETTER(u0, u0, NU)
 GETTER(residuals, res, 4)
 GETTER(x0, x0, NX)
+GETTER(slacks, slk, h->NS * NLAM)
 #undef GETTER
 
 int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam)

@@ -33,7 +33,7 @@ struct QpArgs {
     int B, N, iter_max, nslots, m_act;
     double tol, mu0, tau0;
     // shared
-    const double *Hs, *Gy, *CD, *slot_lb, *slot_ub;
+    const double *Hs, *Gy, *CD, *slot_lb, *slot_ub, *slot_zw, *slot_Zw;
     const int32_t *slot_kc;
     // per instance
     double *x, *u;
@@ -41,7 +41,7 @@ struct QpArgs {
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g, *P, *M, *Mt;
+    double *g, *P, *M, *Mt, *slk;
 };
 
 #define INF_BOUND 1e20
@@ -179,7 +179,7 @@ __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2,
     }
 }
 
-template <int NSLOT>
+template <int NSLOT, int NSOFT>
 __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 {
     extern __shared__ double sm[];
@@ -213,6 +213,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *Mg = a.M + (size_t)b * N * 64, *Mtg = a.Mt + (size_t)b * N * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 24;
+    double *slkb = a.slk + (size_t)b * NS * 24;
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
@@ -267,14 +268,24 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     int s_kc[NSLOT];
     double s_dl[NSLOT], s_du[NSLOT];      // bounds relative to the iterate (+-inf = absent)
     double lam_l[NSLOT], lam_u[NSLOT], t_l[NSLOT], t_u[NSLOT];
+    // soft slots (one-sided by construction, always among the first NSOFT of a lane): slack variable s >= 0 with cost
+    // zw s + 1/2 Zw s^2 and multiplier lam_s; Zw < 0 marks a hard slot
+    constexpr int NSO = (NSOFT > 0) ? NSOFT : 1;
+    double so_zw[NSO], so_Zw[NSO], so_s[NSO], so_ls[NSO], so_rs[NSO], so_ds[NSO], so_dls[NSO], so_pa[NSO];
+#pragma unroll
+    for (int r = 0; r < NSO; r++) { so_zw[r] = 0.0; so_Zw[r] = -1.0; so_s[r] = 1.0; so_ls[r] = 0.0; so_rs[r] = 0.0; so_ds[r] = so_dls[r] = so_pa[r] = 0.0; }
+#define IS_SOFT(r) ((r) < NSOFT && so_Zw[(r) < NSOFT ? (r) : 0] >= 0.0)
+// rows are split (two slots, one lane, one LDS word) only when soft sides exist
+#define SLOT_ACC(dst, v) do { if (NSOFT > 0) (dst) += (v); else (dst) = (v); } while (0)
     double r_ineq = 0.0, r_comp = 0.0;
 #pragma unroll
     for (int r = 0; r < NSLOT; r++) {
         const int s = lane + 64 * r;
         s_kc[r] = -1; s_dl[r] = -INFINITY; s_du[r] = INFINITY;
         lam_l[r] = lam_u[r] = 0.0; t_l[r] = t_u[r] = 1.0;
-        if (s < a.nslots) {
-            const int kc = a.slot_kc[s], k = kc / 12, c = kc % 12;
+        const int kc = (s < a.nslots) ? a.slot_kc[s] : -1;
+        if (kc >= 0) {
+            const int k = kc / 12, c = kc % 12;
             s_kc[r] = kc;
             double cz;
             if (c < 8) cz = xb[k * 8 + c];
@@ -287,8 +298,11 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 cz = fma(a.CD[(k * 2 + c - 10) * 10 + 9], ub[k * 2 + 1], cz);
             }
             const double lb = a.slot_lb[s], ubd = a.slot_ub[s];
-            if (fin(lb)) { s_dl[r] = lb - cz; r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + c] * s_dl[r])); }
-            if (fin(ubd)) { s_du[r] = ubd - cz; r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + 12 + c] * s_du[r])); }
+            bool soft = false;
+            if (r < NSOFT) { so_zw[r < NSOFT ? r : 0] = a.slot_zw[s]; so_Zw[r < NSOFT ? r : 0] = a.slot_Zw[s]; soft = a.slot_Zw[s] >= 0.0; }
+            // soft sides may be violated: they do not count as infeasibility of the iterate
+            if (fin(lb)) { s_dl[r] = lb - cz; if (!soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + c] * s_dl[r])); } }
+            if (fin(ubd)) { s_du[r] = ubd - cz; if (!soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + 12 + c] * s_du[r])); } }
         }
     }
     r_stat = wave_max(r_stat); r_eq = wave_max(r_eq); r_ineq = wave_max(r_ineq); r_comp = wave_max(r_comp);
@@ -324,6 +338,14 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         const bool al = fin(s_dl[r]), au = fin(s_du[r]);
         double tau_c = a.tau0;
         if (al && au) tau_c = fmin(a.tau0, 0.25 * (s_du[r] - s_dl[r]));
+        if (IS_SOFT(r)) {
+            const double slack = al ? rz - s_dl[r] : s_du[r] - rz;
+            const double s0 = fmax(a.tau0, a.tau0 - slack);
+            so_s[r < NSOFT ? r : 0] = s0;
+            so_ls[r < NSOFT ? r : 0] = mu0 / s0;
+            if (al) { t_l[r] = slack + s0; lam_l[r] = mu0 / t_l[r]; } else { t_u[r] = slack + s0; lam_u[r] = mu0 / t_u[r]; }
+            continue;
+        }
         if (al) { t_l[r] = fmax(rz - s_dl[r], tau_c); lam_l[r] = mu0 / t_l[r]; }
         if (au) { t_u[r] = fmax(s_du[r] - rz, tau_c); lam_u[r] = mu0 / t_u[r]; }
     }
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
         for (int e = lane; e < NS * 12; e += 64) cf[e] = 0.0;
         WSYNC();
-        double mu_acc = 0.0;
+        double mu_acc = 0.0, res_gs = 0.0;
         res_d = 0.0; res_m = 0.0;
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
@@ -346,10 +368,17 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             if (s_kc[r] < 0) continue;
             const double rz = row_dot(s_kc[r], z);
             const bool al = fin(s_dl[r]), au = fin(s_du[r]);
-            if (al) { rd_l[r] = rz - t_l[r] - s_dl[r]; mu_acc += lam_l[r] * t_l[r]; res_m = nanmax(res_m, fabs(lam_l[r] * t_l[r])); }
-            if (au) { rd_u[r] = s_du[r] - rz - t_u[r]; mu_acc += lam_u[r] * t_u[r]; res_m = nanmax(res_m, fabs(lam_u[r] * t_u[r])); }
+            const double sv = IS_SOFT(r) ? so_s[r < NSOFT ? r : 0] : 0.0;      // the slack enters its (single) side
+            if (al) { rd_l[r] = rz - t_l[r] - s_dl[r] + sv; mu_acc += lam_l[r] * t_l[r]; res_m = nanmax(res_m, fabs(lam_l[r] * t_l[r])); }
+            if (au) { rd_u[r] = s_du[r] - rz - t_u[r] + sv; mu_acc += lam_u[r] * t_u[r]; res_m = nanmax(res_m, fabs(lam_u[r] * t_u[r])); }
             res_d = nanmax(res_d, nanmax(fabs(rd_l[r]), fabs(rd_u[r])));
-            cf[s_kc[r]] = lam_l[r] - lam_u[r];
+            if (IS_SOFT(r)) {
+                const int q = r < NSOFT ? r : 0;
+                so_rs[q] = so_Zw[q] * so_s[q] + so_zw[q] - (al ? lam_l[r] : lam_u[r]) - so_ls[q];
+                res_gs = nanmax(res_gs, fabs(so_rs[q]));
+                mu_acc += so_ls[q] * so_s[q]; res_m = nanmax(res_m, fabs(so_ls[q] * so_s[q]));
+            }
+            SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));     // the two halves of a split slot share a lane
         }
         WSYNC();
         // ---- stationarity and dynamics residuals ----
@@ -401,6 +430,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             res_g = nanmax(res_g, fabs(v));
         }
         for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e]));
+        res_g = nanmax(res_g, res_gs);
         res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m);
         mu = wave_sum(mu_acc) * inv_m;
         if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; }
@@ -420,15 +450,27 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 if (s_kc[r] < 0) continue;
                 const bool al = fin(s_dl[r]), au = fin(s_du[r]);
                 double c = 0.0;
+                if (IS_SOFT(r)) {
+                    // eliminated slack block: gamma_eff = gam (Z + gam_s)/D, coef_eff = c1 - gam (rs + c1 + c2)/D
+                    const int q = r < NSOFT ? r : 0;
+                    const double lm = al ? lam_l[r] : lam_u[r], tt = al ? t_l[r] : t_u[r], rdv = al ? rd_l[r] : rd_u[r];
+                    const double gm = lm / tt, gs = so_ls[q] / so_s[q], D = so_Zw[q] + gm + gs;
+                    double c1, c2, rsv;
+                    if (pass == 0) { c1 = (lm * tt + lm * rdv) / tt; c2 = so_ls[q]; rsv = so_rs[q]; gam[s_kc[r]] += gm * (so_Zw[q] + gs) / D; }
+                    else { c1 = ((al ? dla_l[r] * dta_l[r] : dla_u[r] * dta_u[r]) - mu_t) / tt; c2 = (so_pa[q] - mu_t) / so_s[q]; rsv = 0.0; }
+                    c = c1 - gm * (rsv + c1 + c2) / D;
+                    cf[s_kc[r]] += al ? c : -c;
+                    continue;
+                }
                 if (pass == 0) {
                     if (al) c += (lam_l[r] * t_l[r] + lam_l[r] * rd_l[r]) / t_l[r];
                     if (au) c -= (lam_u[r] * t_u[r] + lam_u[r] * rd_u[r]) / t_u[r];
-                    gam[s_kc[r]] = (al ? lam_l[r] / t_l[r] : 0.0) + (au ? lam_u[r] / t_u[r] : 0.0);
+                    SLOT_ACC(gam[s_kc[r]], (al ? lam_l[r] / t_l[r] : 0.0) + (au ? lam_u[r] / t_u[r] : 0.0));
                 } else {
                     if (al) c += (dla_l[r] * dta_l[r] - mu_t) / t_l[r];
                     if (au) c -= (dla_u[r] * dta_u[r] - mu_t) / t_u[r];
                 }
-                cf[s_kc[r]] = c;
+                SLOT_ACC(cf[s_kc[r]], c);
             }
             WSYNC();
             for (int e = lane; e < NS * 10; e += 64) {
@@ -612,6 +654,27 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 dlam_l[r] = dlam_u[r] = dt_l[r] = dt_u[r] = 0.0;
                 if (s_kc[r] < 0) continue;
                 const double drz = row_dot(s_kc[r], dz);
+                if (IS_SOFT(r)) {
+                    const int q = r < NSOFT ? r : 0;
+                    const bool al = fin(s_dl[r]);
+                    const double lm = al ? lam_l[r] : lam_u[r], tt = al ? t_l[r] : t_u[r], rdv = al ? rd_l[r] : rd_u[r];
+                    const double y = al ? drz : -drz;
+                    const double gm = lm / tt, gs = so_ls[q] / so_s[q], D = so_Zw[q] + gm + gs;
+                    const double rm1 = (pass == 0) ? lm * tt : lm * tt + (al ? dla_l[r] * dta_l[r] : dla_u[r] * dta_u[r]) - mu_t;
+                    const double rm2 = (pass == 0) ? so_ls[q] * so_s[q] : so_ls[q] * so_s[q] + so_pa[q] - mu_t;
+                    const double c1 = (rm1 + lm * rdv) / tt, c2 = rm2 / so_s[q];
+                    const double dsv = -(so_rs[q] + c1 + c2) / D - gm / D * y;
+                    const double dlsv = -(rm2 + so_ls[q] * dsv) / so_s[q];
+                    const double dtv = y + dsv + rdv;
+                    const double dlv = -(rm1 + lm * dtv) / tt;
+                    so_ds[q] = dsv; so_dls[q] = dlsv;
+                    if (al) { dt_l[r] = dtv; dlam_l[r] = dlv; } else { dt_u[r] = dtv; dlam_u[r] = dlv; }
+                    if (dsv < 0.0) amax = fmin(amax, -so_s[q] / dsv);
+                    if (dlsv < 0.0) amax = fmin(amax, -so_ls[q] / dlsv);
+                    if (dtv < 0.0) amax = fmin(amax, -tt / dtv);
+                    if (dlv < 0.0) amax = fmin(amax, -lm / dlv);
+                    continue;
+                }
                 if (fin(s_dl[r])) {
                     const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + dla_l[r] * dta_l[r] - mu_t;
                     dt_l[r] = drz + rd_l[r];
@@ -636,6 +699,11 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     if (s_kc[r] < 0) continue;
                     if (fin(s_dl[r])) mu_aff += (lam_l[r] + amax * dlam_l[r]) * (t_l[r] + amax * dt_l[r]);
                     if (fin(s_du[r])) mu_aff += (lam_u[r] + amax * dlam_u[r]) * (t_u[r] + amax * dt_u[r]);
+                    if (IS_SOFT(r)) {
+                        const int q = r < NSOFT ? r : 0;
+                        so_pa[q] = so_dls[q] * so_ds[q];
+                        mu_aff += (so_ls[q] + amax * so_dls[q]) * (so_s[q] + amax * so_ds[q]);
+                    }
                 }
                 mu_aff = wave_sum(mu_aff) * inv_m;
                 const double ratio = (mu > 0.0) ? mu_aff / mu : 0.0;
@@ -654,6 +722,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             if (s_kc[r] < 0) continue;
             if (fin(s_dl[r])) { lam_l[r] = fma(alpha, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
             if (fin(s_du[r])) { lam_u[r] = fma(alpha, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
+            if (IS_SOFT(r)) { const int q = r < NSOFT ? r : 0; so_s[q] = fma(alpha, so_ds[q], so_s[q]); so_ls[q] = fma(alpha, so_dls[q], so_ls[q]); }
         }
         WSYNC();
     }
@@ -671,6 +740,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (wave_max(bad) > 0.0) st = 1;
     }
     double *xw = a.x + (size_t)b * NS * 8, *uw = a.u + (size_t)b * N * 2;
+    if (NSOFT > 0) {        // slacks of a failed instance read 0; an all-hard table never touches the array
+        for (int e = lane; e < NS * 24; e += 64) slkb[e] = 0.0;
+    }
     if (st == 0) {
         for (int e = lane; e < NS * 10; e += 64) {
             const int k = e / 10, j = e % 10;
@@ -684,8 +756,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
             const int k = s_kc[r] / 12, c = s_kc[r] % 12;
-            lamb[k * 24 + c] = lam_l[r];
-            lamb[k * 24 + 12 + c] = lam_u[r];
+            if (fin(s_dl[r])) lamb[k * 24 + c] = lam_l[r];
+            if (fin(s_du[r])) lamb[k * 24 + 12 + c] = lam_u[r];
+            if (IS_SOFT(r)) slkb[k * 24 + (fin(s_dl[r]) ? c : 12 + c)] = so_s[r < NSOFT ? r : 0];
         }
     }
     __syncthreads();
@@ -698,7 +771,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 int ihm2_launch_qp(ihm2mpc_handle *h)
 {
     QpArgs a;
-    a.B = h->B; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max; a.nslots = h->nslots; a.m_act = h->m_act;
+    a.B = h->B; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max; a.nslots = h->nslot_lane * 64; a.m_act = h->m_act;
     a.tol = h->cfg.ipm_tol; a.mu0 = h->cfg.ipm_mu0; a.tau0 = h->cfg.ipm_tau0;
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
@@ -707,15 +780,18 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     const int N = h->N, NS = h->NS;
     const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 10) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
     if (lds > 160 * 1024) return 1;
-    const int per_lane = (h->nslots + 63) / 64;
-    if (per_lane <= 5) {
-        (void)hipFuncSetAttribute((const void *)k_qp_wave<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_qp_wave<5>, dim3(h->B), dim3(64), lds, h->stream, a);
-    } else if (per_lane <= 8) {
-        (void)hipFuncSetAttribute((const void *)k_qp_wave<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_qp_wave<8>, dim3(h->B), dim3(64), lds, h->stream, a);
-    } else {
-        return 2;
-    }
+    a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
+    const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
+#define LAUNCH_QP(NS_, NO_)                                                                                              \
+    do {                                                                                                                 \
+        (void)hipFuncSetAttribute((const void *)k_qp_wave<NS_, NO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_qp_wave<NS_, NO_>), dim3(h->B), dim3(64), lds, h->stream, a);                              \
+    } while (0)
+    if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0);
+    else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0);
+    else if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2);
+    else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4);
+    else return 2;
+#undef LAUNCH_QP
     return 0;
 }

@@ -98,6 +98,21 @@ class BatchedOcpSolver:
         d = self.data
         arrs = [_f64(getattr(d, n)) for n in ("lbx", "ubx", "lbu", "ubu", "C", "D", "lg", "ug")]
         _lib.check(self.lib.ihm2mpc_set_bounds(self._h, *[_ptr(a) for a in arrs]))
+        self._push_soft()
+
+    def _push_soft(self):
+        d = self.data
+        if getattr(d, "soft_Z", None) is None or not np.any(np.asarray(d.soft_Z) >= 0.0):
+            _lib.check(self.lib.ihm2mpc_set_soft(self._h, None, None))
+            return
+        z = _f64(d.soft_z, (self.N + 1, NLAM), "soft_z"); Z = _f64(d.soft_Z, (self.N + 1, NLAM), "soft_Z")
+        _lib.check(self.lib.ihm2mpc_set_soft(self._h, _ptr(z), _ptr(Z)))
+
+    def set_soft(self, soft_z=None, soft_Z=None):
+        """Soft constraint sides, ``(N+1, 24)`` each (12 lower then 12 upper; ``soft_Z < 0`` = hard); ``None`` = all hard."""
+        self.data.soft_z = None if soft_z is None else np.asarray(soft_z, dtype=np.float64)
+        self.data.soft_Z = None if soft_Z is None else np.asarray(soft_Z, dtype=np.float64)
+        self._push_soft()
 
     def set_tracks(self, s_ref, kappa_ref):
         self._s_ref = _f64(np.atleast_2d(s_ref), (self.ntracks, self.nknots), "s_ref")
@@ -193,6 +208,10 @@ class BatchedOcpSolver:
         pi = np.empty((self.B, self.N + 1, NX)); lam = np.empty((self.B, self.N + 1, NLAM))
         _lib.check(self.lib.ihm2mpc_get_multipliers(self._h, _ptr(pi), _ptr(lam)))
         return pi, lam
+
+    def get_slacks(self):
+        """Slack of each soft constraint side after the last QP, ``(B, N+1, 24)`` (0 for hard sides)."""
+        return self._get(self.lib.ihm2mpc_get_slacks, (self.B, self.N + 1, NLAM))
 
     def get_status(self):
         out = np.empty(self.B, dtype=np.int32)

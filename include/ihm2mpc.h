@@ -93,6 +93,11 @@ int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e); 
 int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, const double *lbu,
                        const double *ubu, const double *C, const double *D, const double *lg,
                        const double *ug);
+/* SOFT constraint sides (AcadosOcpConstraints idxsbx / idxsbx_e / idxsg with AcadosOcpCost zl, zu, Zl, Zu --
+ * declared by the reference's OCP class, python/mpc.py:58-90 uses hard sides only): soft_z, soft_Z (N+1,24) per
+ * one-sided constraint, 12 lower sides [x(8) u(2) g(2)] then 12 upper sides.  A side with soft_Z >= 0 carries a
+ * slack s >= 0 with cost soft_z*s + 1/2*soft_Z*s^2; soft_Z < 0 = hard.  NULL, NULL = all hard (the default). */
+int ihm2mpc_set_soft(ihm2mpc_handle *h, const double *soft_z, const double *soft_Z);
 
 /* ---- per-instance data ---- */
 int ihm2mpc_set_x0(ihm2mpc_handle *h, const double *x0);         /* (B,8) */
@@ -128,6 +133,7 @@ int ihm2mpc_get_status(ihm2mpc_handle *h, int32_t *status);     /* (B) */
 int ihm2mpc_get_qp_iter(ihm2mpc_handle *h, int32_t *qp_iter);   /* (B) */
 int ihm2mpc_get_residuals(ihm2mpc_handle *h, double *res);      /* (B,4): stat, eq, ineq, comp */
 int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam);
+int ihm2mpc_get_slacks(ihm2mpc_handle *h, double *sl);         /* (B,N+1,24) slack of each soft side after the last QP */
 /* milliseconds of the last solve(): [0] total, [1] linearize, [2] qp+update (HIP events) */
 int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n);
 

@@ -245,3 +245,83 @@ def test_fdyn6_rti_step_matches_oracle(setup_dyn):
     assert _rel(xg[ok], x[ok]) < 1e-6          # tolerance 1e-6 relative (north star: 1e-5)
     assert _rel(ug[ok], u[ok]) < 1e-6
     assert _rel(s.get_residuals(), out["res"]) < 1e-8
+
+
+# ---- soft constraint sides (AcadosOcp idxsbx / idxsg / idxsbx_e with zl, zu, Zl, Zu): eliminated slack blocks ----
+@pytest.fixture(scope="module")
+def setup_soft(track):
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    B = 70
+    ocp = make_ocp(n_max=0.3)           # the sampled |n| <= 0.5 violates the track bound: slacks are active
+    c = ocp.constraints
+    c.idxsbx = np.array([0, 1])         # positions in idxbx: n (both sides soft) and v_x
+    c.idxsg = np.array([1])             # the steering-rate row
+    ocp.cost.zl = np.array([50.0, 10.0, 5.0]); ocp.cost.zu = np.array([50.0, 10.0, 5.0])
+    ocp.cost.Zl = np.array([200.0, 0.0, 20.0]); ocp.cost.Zu = np.array([200.0, 0.0, 20.0])
+    c.idxsbx_e = np.array([0])
+    ocp.cost.zl_e = np.array([50.0]); ocp.cost.zu_e = np.array([50.0])
+    ocp.cost.Zl_e = np.array([200.0]); ocp.cost.Zu_e = np.array([200.0])
+    data = ocp.flatten()
+    # make it a MIXED row as well: lower side of v_x hard again, upper side soft
+    data.soft_Z[:, 3] = -1.0
+    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    solver.set_soft(data.soft_z, data.soft_Z)
+    P = orc.OracleProblem(data.as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, B, seed=4242)
+    solver.set_x0(x0)
+    solver.init_guess()
+    return dict(solver=solver, P=P, x0=x0, B=B, data=data, orc=orc)
+
+
+def test_soft_rti_step_matches_oracle(setup_soft):
+    s, P, B, x0 = setup_soft["solver"], setup_soft["P"], setup_soft["B"], setup_soft["x0"]
+    x, u = s.get_x(), s.get_u()
+    x_in, u_in = x.copy(), u.copy()
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+    s.set_yref(yref); s.set_yref_e(yref_e); s.set_multipliers(None, None)
+    status = s.solve()
+    xg, ug = s.get_x(), s.get_u()
+    out = P.rti_step(x, u, x0, yref, yref_e)
+    np.testing.assert_array_equal(status, out["status"])
+    np.testing.assert_array_equal(s.get_qp_iter(), out["qp_iter"])
+    ok = status == 0
+    assert ok.sum() >= 0.9 * B          # with hard sides most of these QPs are infeasible (|n0| > n_max)
+    assert _rel(xg[ok], x[ok]) < 1e-7   # tolerance 1e-7 relative (north star: 1e-5)
+    assert _rel(ug[ok], u[ok]) < 1e-7
+    assert _rel(s.get_residuals(), out["res"]) < 1e-9
+    _, lam = s.get_multipliers()
+    assert np.max(np.abs(lam[ok] - out["lam"][ok])) / (1.0 + np.abs(out["lam"]).max()) < 1e-6
+    # slack values of individual instances against the oracle's QP solve
+    sl = s.get_slacks()
+    d = setup_soft["data"]
+    assert np.all(sl[:, d.soft_Z < 0.0] == 0.0)
+    n_viol = 0
+    for i in np.flatnonzero(ok)[:6]:
+        qp = P.build_qp(x_in[i], u_in[i], x0[i], yref[i], yref_e[i])
+        ref = setup_soft["orc"].qp_solve(qp["H"], qp["g"], qp["A"], qp["Bm"], qp["b"], qp["dx0"], qp["R"], qp["dl"], qp["du"],
+                                         soft_z=d.soft_z, soft_Z=d.soft_Z, iter_max=P.p.ipm_iter_max, tol=P.p.ipm_tol,
+                                         mu0=P.p.ipm_mu0, tau0=P.p.ipm_tau0)
+        assert np.max(np.abs(sl[i] - ref["sl"])) < 1e-6 * (1.0 + np.abs(ref["sl"]).max())
+        n_viol += int(ref["sl"].max() > 1e-3)
+    assert n_viol >= 1                  # the test is not vacuous: some slack is really used
+    # the soft n-bound is violated by the solution exactly by its slack (complementary sides)
+    n_pred = xg[ok][:, 1:, 1]
+    over = np.maximum(np.abs(n_pred) - 0.3, 0.0)
+    used = np.maximum(sl[ok][:, 1:, 1], sl[ok][:, 1:, 13])
+    assert np.max(over - used) < 1e-6
+
+
+def test_soft_sides_can_be_switched_off_again(setup_soft, track):
+    s, B = setup_soft["solver"], setup_soft["B"]
+    s.set_soft(None, None)
+    s.set_x0(setup_soft["x0"]); s.init_guess(); s.set_multipliers(None, None)
+    st_hard = s.solve()
+    assert np.all(s.get_slacks() == 0.0)
+    d = setup_soft["data"]
+    s.set_soft(d.soft_z, d.soft_Z)
+    s.set_x0(setup_soft["x0"]); s.init_guess(); s.set_multipliers(None, None)
+    st_soft = s.solve()
+    assert (st_soft == 0).sum() > (st_hard == 0).sum()       # |n0| > n_max is infeasible with hard sides
