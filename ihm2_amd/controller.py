@@ -105,6 +105,7 @@ class IHM2Controller(Controller):
         nlp_solver_type: str = "SQP_RTI",
         nlp_solver_max_iter: int = 1,
         terminal_bounds: str = "reference",
+        soft_state_bounds: tuple | None = None,
     ) -> None:
         self.Nf, self.dt, self.s_target, self.B = Nf, dt, s_target, int(batch_size)
         self.config = Controller.Config(horizon_size=Nf, sampling_time=dt)
@@ -122,6 +123,20 @@ class IHM2Controller(Controller):
             c.idxbx_e, c.lbx_e, c.ubx_e = c.idxbx.copy(), c.lbx.copy(), c.ubx.copy()
         elif terminal_bounds != "reference":
             raise ValueError("terminal_bounds must be 'reference' or 'stage'")
+        if soft_state_bounds is not None:
+            # not in the reference (python/mpc.py:58-90 has hard sides only): soften the path constraints on the
+            # PLANT states -- the n and v_x boxes of every stage and the whole terminal box -- with the penalty
+            # z s + 1/2 Z s^2, soft_state_bounds = (z, Z).  The actuator-state boxes, the input boxes and the rate rows
+            # stay hard and can always be met, so the QP is feasible from any plant state.
+            z_pen, Z_pen = (float(v) for v in soft_state_bounds)
+            c = ocp.constraints
+            pos = np.flatnonzero(np.isin(np.asarray(c.idxbx), (1, 3)))
+            nsb, nsb_e = len(pos), len(c.idxbx_e)
+            c.idxsbx, c.idxsbx_e = pos, np.arange(nsb_e)
+            ocp.cost.zl = ocp.cost.zu = np.full(nsb, z_pen)
+            ocp.cost.Zl = ocp.cost.Zu = np.full(nsb, Z_pen)
+            ocp.cost.zl_e = ocp.cost.zu_e = np.full(nsb_e, z_pen)
+            ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(nsb_e, Z_pen)
         opts = AcadosOcpOptions()                      # python/main.py:227-238, with ERK x M for IRK
         opts.tf = Nf * dt
         opts.nlp_solver_type = nlp_solver_type
