@@ -68,3 +68,6 @@ NU = 2
 NY = 12
 NY_E = 8
 NG = 2
+NH = 2            # nonlinear track-boundary rows (old/generate_acaods_interface.py:191-212)
+NC = 8 + NU + NG + NH   # two-sided constraint rows per stage: x boxes, u boxes, general rows, track rows
+NLAM = 2 * NC     # one-sided multipliers per stage: NC lower sides, then NC upper sides

@@ -143,12 +143,13 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(Hs, NS * 100); DA(Gy, NS * 120); DA(lbx, NS * 8); DA(ubx, NS * 8); DA(lbu, N * 2); DA(ubu, N * 2);
     DA(CD, N * 20); DA(lg, N * 2); DA(ug, N * 2);
     DA(slot_kc, MAX_SLOTS); DA(slot_lb, MAX_SLOTS); DA(slot_ub, MAX_SLOTS); DA(slot_zw, MAX_SLOTS); DA(slot_Zw, MAX_SLOTS);
-    DA(slk, B * NS * 24);
-    h->host_lb = new double[NS * 12]; h->host_ub = new double[NS * 12];
-    h->host_sz = new double[NS * 24]; h->host_sZ = new double[NS * 24];
-    for (size_t i = 0; i < NS * 24; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
+    DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2);
+    h->host_lb = new double[NS * NC]; h->host_ub = new double[NS * NC];
+    h->host_sz = new double[NS * NLAM]; h->host_sZ = new double[NS * NLAM];
+    for (size_t i = 0; i < NS * NC; i++) { h->host_lb[i] = -INFINITY; h->host_ub[i] = INFINITY; }
+    for (size_t i = 0; i < NS * NLAM; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
-    DA(pi, B * NS * 8); DA(lam, B * NS * 24); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(u0, B * 2);
+    DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(u0, B * 2);
     DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, B * N * 64); DA(q_Mt, B * N * 64); DA(scratch, B * 24);
 #undef DA
     *out = h;
@@ -161,7 +162,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
                     h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->q_Mt, h->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
@@ -269,10 +270,10 @@ static int rebuild_slots(ihm2mpc_handle *h)
     for (int pass = 0; pass < 2; pass++)
         for (int k = 0; k < NS; k++)
             for (int c = 0; c < NC; c++) {
-                const double lb = h->host_lb[k * 12 + c], ub = h->host_ub[k * 12 + c];
+                const double lb = h->host_lb[k * NC + c], ub = h->host_ub[k * NC + c];
                 const bool fl = std::isfinite(lb), fu = std::isfinite(ub);
                 if (!fl && !fu) continue;
-                const bool sl = fl && h->host_sZ[k * 24 + c] >= 0.0, su = fu && h->host_sZ[k * 24 + 12 + c] >= 0.0;
+                const bool sl = fl && h->host_sZ[k * NLAM + c] >= 0.0, su = fu && h->host_sZ[k * NLAM + NC + c] >= 0.0;
                 if ((sl || su) != (pass == 0)) continue;
                 int best = 0;       // least-loaded lane; ties -> lowest lane (round-robin for an all-hard table)
                 for (int l = 1; l < 64; l++) {
@@ -281,10 +282,10 @@ static int rebuild_slots(ihm2mpc_handle *h)
                     if (pass == 0 ? (fewer_soft || (same_soft && fewer)) : fewer) best = l;
                 }
                 std::vector<Slot> &L = lanes[best];
-                if (!sl && !su) L.push_back({k * 12 + c, lb, ub, 0.0, -1.0});
+                if (!sl && !su) L.push_back({k * 16 + c, lb, ub, 0.0, -1.0});
                 else {
-                    if (fl) L.push_back({k * 12 + c, lb, INFINITY, sl ? h->host_sz[k * 24 + c] : 0.0, sl ? h->host_sZ[k * 24 + c] : -1.0});
-                    if (fu) L.push_back({k * 12 + c, -INFINITY, ub, su ? h->host_sz[k * 24 + 12 + c] : 0.0, su ? h->host_sZ[k * 24 + 12 + c] : -1.0});
+                    if (fl) L.push_back({k * 16 + c, lb, INFINITY, sl ? h->host_sz[k * NLAM + c] : 0.0, sl ? h->host_sZ[k * NLAM + c] : -1.0});
+                    if (fu) L.push_back({k * 16 + c, -INFINITY, ub, su ? h->host_sz[k * NLAM + NC + c] : 0.0, su ? h->host_sZ[k * NLAM + NC + c] : -1.0});
                 }
                 nsoft[best] += (int)sl + (int)su;
                 m_act += (int)fl + (int)fu + (int)sl + (int)su;
@@ -334,13 +335,13 @@ int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, 
             for (int j = 0; j < NU; j++) CD[((size_t)k * 2 + r) * 10 + 8 + j] = D[((size_t)k * 2 + r) * NU + j];
         }
     for (int k = 0; k < NS; k++)
-        for (int c = 0; c < NC; c++) {
+        for (int c = 0; c < 12; c++) {       // rows 12, 13 belong to set_path_constraints
             double lb = -INFINITY, ub = INFINITY;
             if (c < 8) { if (k >= 1) { lb = lbx[k * 8 + c]; ub = ubx[k * 8 + c]; } }
             else if (c < 10) { if (k < N) { lb = lbu[k * 2 + c - 8]; ub = ubu[k * 2 + c - 8]; } }
             else { if (k < N) { lb = lg[k * 2 + c - 10]; ub = ug[k * 2 + c - 10]; } }
-            h->host_lb[k * 12 + c] = (std::fabs(lb) < 1e20) ? lb : -INFINITY;
-            h->host_ub[k * 12 + c] = (std::fabs(ub) < 1e20) ? ub : INFINITY;
+            h->host_lb[k * NC + c] = (std::fabs(lb) < 1e20) ? lb : -INFINITY;
+            h->host_ub[k * NC + c] = (std::fabs(ub) < 1e20) ? ub : INFINITY;
         }
     if (rebuild_slots(h)) return -1;
     if (upload_shared(h, lbx, h->lbx, (size_t)NS * 8) || upload_shared(h, ubx, h->ubx, (size_t)NS * 8) ||
@@ -355,7 +356,7 @@ int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, 
 int ihm2mpc_set_soft(ihm2mpc_handle *h, const double *soft_z, const double *soft_Z)
 {
     CHECK_H(h);
-    const int n = h->NS * 24;
+    const int n = h->NS * NLAM;
     if ((soft_z == nullptr) != (soft_Z == nullptr)) return fail("soft_z and soft_Z must both be given or both be NULL");
     for (int i = 0; i < n; i++) {
         const double Z = soft_Z ? soft_Z[i] : -1.0, z = soft_z ? soft_z[i] : 0.0;
@@ -364,6 +365,30 @@ int ihm2mpc_set_soft(ihm2mpc_handle *h, const double *soft_z, const double *soft
         h->host_sz[i] = z; h->host_sZ[i] = Z;
     }
     HIP_TRY(hipMemsetAsync(h->slk, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
+    if (h->bounds_set && rebuild_slots(h)) return -1;
+    return 0;
+}
+
+int ihm2mpc_set_path_constraints(ihm2mpc_handle *h, int32_t enable, double car_length, double car_width, const double *widths,
+                                 const double *lh, const double *uh)
+{
+    CHECK_H(h);
+    const int NS = h->NS;
+    if (enable) {
+        if (!widths || !lh || !uh) return fail("null argument");
+        if (!(car_length >= 0.0) || !(car_width >= 0.0)) return fail("car_length and car_width must be non-negative");
+        for (int i = 0; i < NH; i++) if (lh[i] > uh[i]) return fail("lh > uh at row %d", i);
+        for (int t = 0; t < h->cfg.ntracks * 2; t++) if (!(widths[t] > 0.0)) return fail("track width %d is not positive", t);
+        if (upload_shared(h, widths, h->widths, (size_t)h->cfg.ntracks * 2)) return -1;
+        h->car_L = car_length; h->car_W = car_width;
+    }
+    h->path_on = enable ? 1 : 0;
+    for (int k = 0; k < NS; k++)
+        for (int i = 0; i < NH; i++) {
+            const bool on = enable && k >= 1;       // x_0 is fixed: the rows of stage 0 are constants
+            h->host_lb[k * NC + 12 + i] = (on && std::fabs(lh[i]) < 1e20) ? lh[i] : -INFINITY;
+            h->host_ub[k * NC + 12 + i] = (on && std::fabs(uh[i]) < 1e20) ? uh[i] : INFINITY;
+        }
     if (h->bounds_set && rebuild_slots(h)) return -1;
     return 0;
 }

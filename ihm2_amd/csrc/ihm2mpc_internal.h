@@ -18,8 +18,9 @@
 #define NZ 10
 #define NY 12
 #define NG 2
-#define NC 12   // two-sided constraint slots per stage: 8 state boxes, 2 input boxes, 2 general rows
-#define NLAM 24
+#define NH 2
+#define NC 14   // two-sided constraint rows per stage: 8 state boxes, 2 input boxes, 2 general rows, 2 track rows
+#define NLAM 28
 #define MAX_SLOTS 640   // 10 per lane
 #define LIN_REC 88   // doubles per (instance, interval) linearisation record: A (64) | B (16) | b (8)
 
@@ -43,12 +44,16 @@ struct ihm2mpc_handle {
     // -- laid out for the QP kernel: entry lane + 64 r belongs to lane `lane`; a lane's soft slots come first --
     int nslots, m_act;             // m_act: number of one-sided inequality pairs (finite sides + one per soft slack)
     int nslot_lane, nsoft_lane;    // slots per lane / soft slots per lane (maxima over the 64 lanes)
-    int32_t *slot_kc;              // (nslot_lane*64) stage * 12 + row, -1 = padding
+    int32_t *slot_kc;              // (nslot_lane*64) stage * 16 + row, -1 = padding
     double *slot_lb, *slot_ub;     // raw bounds, +-inf if that side is absent (soft slots are one-sided)
     double *slot_zw, *slot_Zw;     // slack cost zw s + 1/2 Zw s^2 of a soft slot; Zw < 0 = hard slot
     // host copies the table is rebuilt from (set_bounds / set_soft may come in either order)
-    double *host_lb, *host_ub;     // (NS*12) per (stage, row), +-inf = absent
-    double *host_sz, *host_sZ;     // (NS*24) per one-sided constraint: 12 lower then 12 upper
+    double *host_lb, *host_ub;     // (NS*NC) per (stage, row), +-inf = absent
+    double *host_sz, *host_sZ;     // (NS*NLAM) per one-sided constraint: NC lower then NC upper
+    // nonlinear track-boundary rows (rows 12, 13 of the stages 1..N)
+    int path_on;
+    double car_L, car_W, lh[NH], uh[NH];
+    double *widths;                // (ntracks, 2) = (w_R, w_L), device
 
     // ---- per-instance state, instance-major ----
     double *x;      // (B,NS,8)
@@ -57,8 +62,8 @@ struct ihm2mpc_handle {
     double *yref;   // (B,N,12)
     double *yref_e; // (B,8)
     double *pi;     // (B,NS,8)
-    double *lam;    // (B,NS,24)
-    double *slk;    // (B,NS,24) slack values of the soft sides after the last QP (0 for hard sides)
+    double *lam;    // (B,NS,28)
+    double *slk;    // (B,NS,28) slack values of the soft sides after the last QP (0 for hard sides)
     double *res;    // (B,4)
     int32_t *status, *qp_iter;   // (B)
     double *u0;     // (B,2) first control of the last solve

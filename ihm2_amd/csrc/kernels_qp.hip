@@ -42,6 +42,10 @@ struct QpArgs {
     int32_t *status, *qp_iter;
     const double *lin;
     double *g, *P, *M, *Mt, *slk;
+    // track rows
+    const int32_t *track_id;
+    const double *widths;
+    double car_L, car_W;
 };
 
 #define INF_BOUND 1e20
@@ -179,13 +183,16 @@ __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2,
     }
 }
 
-template <int NSLOT, int NSOFT>
+template <int NSLOT, int NSOFT, int PATH>
 __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 {
     extern __shared__ double sm[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, NS = N + 1;
     if (b >= a.B) return;
+    // constraint rows per stage held in LDS: 8 x boxes, 2 u boxes, 2 general rows (+ 2 track rows); the multiplier arrays in
+    // HBM always have the full NLAM = 28 columns (14 lower sides, then 14 upper sides)
+    constexpr int NCK = PATH ? 14 : 12;
 
     // ---- LDS carve-up (doubles) ----
     double *z = sm;                  // NS*10  QP iterate
@@ -193,9 +200,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *pi = gt + NS * 10;       // NS*8   QP costates
     double *pv = pi + NS * 8;        // NS*8   Riccati vector p_k, then dpi_k
     double *rb = pv + NS * 8;        // N*8    dynamics residual
-    double *gam = rb + N * 8;        // NS*12  barrier weights per constraint slot
-    double *cf = gam + NS * 12;      // NS*12  lam_l - lam_u, then gradient coefficients
-    double *dz = cf + NS * 12;       // NS*10  step
+    double *gam = rb + N * 8;        // NS*NCK barrier weights per constraint slot
+    double *cf = gam + NS * NCK;     // NS*NCK lam_l - lam_u, then gradient coefficients
+    double *dz = cf + NS * NCK;      // NS*10  step
     double *kff = dz + NS * 10;      // N*2
     double *Kl = kff + N * 2;        // N*16   K_k = Guu^-1 Gux
     double *Ginv = Kl + N * 16;      // N*4    Guu^-1 (3 used)
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *Pn = stage2 + 2 * LIN_REC; // 64   P_{k+1}
     double *Ws = Pn + 64;            // 80     [l][10]
     double *Gs = Ws + 80;            // 100
+    double *hc = Gs + 100;           // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
 
     const double *xb = a.x + (size_t)b * NS * 8;
     const double *ub = a.u + (size_t)b * N * 2;
@@ -212,12 +220,27 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *Pg = a.P + (size_t)b * NS * 64;
     double *Mg = a.M + (size_t)b * N * 64, *Mtg = a.Mt + (size_t)b * N * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
-    double *lamb = a.lam + (size_t)b * NS * 24;
-    double *slkb = a.slk + (size_t)b * NS * 24;
+    double *lamb = a.lam + (size_t)b * NS * 28;
+    double *slkb = a.slk + (size_t)b * NS * 28;
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
     double sg = 1.0, sb = 1.0, r_stat = 0.0, r_eq = 0.0;
+    double w_R = 0.0, w_L = 0.0;
+    if (PATH) {
+        // track rows (old/generate_acaods_interface.py:191-212) at the iterate, stages 1..N:
+        //   h_R = n - L/2 sin|psi| + W/2 cos(psi) - w_R ,  h_L = -n + L/2 sin|psi| + W/2 cos(psi) - w_L
+        // gradients (1, a_R) and (-1, a_L) in (n, psi); d|psi| = sign(psi), sign(0) = 0
+        const int tid = a.track_id[b];
+        w_R = a.widths[tid * 2 + 0]; w_L = a.widths[tid * 2 + 1];
+        for (int k = lane; k < NS; k += 64) {
+            const double psi = xb[k * 8 + 2], sgn = (psi > 0.0) - (psi < 0.0);
+            const double dfoot = -0.5 * a.car_L * cos(fabs(psi)) * sgn, dlat = -0.5 * a.car_W * sin(psi);
+            hc[k * 2 + 0] = (k >= 1) ? dfoot + dlat : 0.0;
+            hc[k * 2 + 1] = (k >= 1) ? -dfoot + dlat : 0.0;
+        }
+        WSYNC();
+    }
     for (int e = lane; e < NS * 10; e += 64) {
         const int k = e / 10, j = e % 10;
         double acc = 0.0;
@@ -245,10 +268,14 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             for (int l = 0; l < 8; l++) st = fma((j < 8) ? rec[l * 8 + j] : rec[64 + l * 2 + (j - 8)], pib[(k + 1) * 8 + l], st);
         }
         if (j < 8) st -= pib[k * 8 + j];
-        st -= lamb[k * 24 + j] - lamb[k * 24 + 12 + j];
+        st -= lamb[k * 28 + j] - lamb[k * 28 + 14 + j];
         if (k < N) {
-            st = fma(-a.CD[(k * 2 + 0) * 10 + j], lamb[k * 24 + 10] - lamb[k * 24 + 22], st);
-            st = fma(-a.CD[(k * 2 + 1) * 10 + j], lamb[k * 24 + 11] - lamb[k * 24 + 23], st);
+            st = fma(-a.CD[(k * 2 + 0) * 10 + j], lamb[k * 28 + 10] - lamb[k * 28 + 24], st);
+            st = fma(-a.CD[(k * 2 + 1) * 10 + j], lamb[k * 28 + 11] - lamb[k * 28 + 25], st);
+        }
+        if (PATH && (j == 1 || j == 2)) {
+            const double l12 = lamb[k * 28 + 12] - lamb[k * 28 + 26], l13 = lamb[k * 28 + 13] - lamb[k * 28 + 27];
+            st -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
         }
         if (counted) r_stat = fmax(r_stat, fabs(st));
     }
@@ -285,12 +312,16 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         lam_l[r] = lam_u[r] = 0.0; t_l[r] = t_u[r] = 1.0;
         const int kc = (s < a.nslots) ? a.slot_kc[s] : -1;
         if (kc >= 0) {
-            const int k = kc / 12, c = kc % 12;
-            s_kc[r] = kc;
+            const int k = kc >> 4, c = kc & 15;
+            s_kc[r] = k * NCK + c;
             double cz;
             if (c < 8) cz = xb[k * 8 + c];
             else if (c < 10) cz = ub[k * 2 + c - 8];
-            else {
+            else if (c >= 12) {
+                const double n = xb[k * 8 + 1], psi = xb[k * 8 + 2];
+                const double foot = -0.5 * a.car_L * sin(fabs(psi)), lat = 0.5 * a.car_W * cos(psi);
+                cz = (c == 12) ? n + foot + lat - w_R : -n - foot + lat - w_L;
+            } else {
                 cz = 0.0;
 #pragma unroll
                 for (int j = 0; j < 8; j++) cz = fma(a.CD[(k * 2 + c - 10) * 10 + j], xb[k * 8 + j], cz);
@@ -301,8 +332,8 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             bool soft = false;
             if (r < NSOFT) { so_zw[r < NSOFT ? r : 0] = a.slot_zw[s]; so_Zw[r < NSOFT ? r : 0] = a.slot_Zw[s]; soft = a.slot_Zw[s] >= 0.0; }
             // soft sides may be violated: they do not count as infeasibility of the iterate
-            if (fin(lb)) { s_dl[r] = lb - cz; if (!soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + c] * s_dl[r])); } }
-            if (fin(ubd)) { s_du[r] = ubd - cz; if (!soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 24 + 12 + c] * s_du[r])); } }
+            if (fin(lb)) { s_dl[r] = lb - cz; if (!soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + c] * s_dl[r])); } }
+            if (fin(ubd)) { s_du[r] = ubd - cz; if (!soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + 14 + c] * s_du[r])); } }
         }
     }
     r_stat = wave_max(r_stat); r_eq = wave_max(r_eq); r_ineq = wave_max(r_ineq); r_comp = wave_max(r_comp);
@@ -318,8 +349,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
     // R_c . v of the slot (k, c) for a stage-major vector v[NS][10] in LDS
     auto row_dot = [&](int kc, const double *v) -> double {
-        const int k = kc / 12, c = kc % 12;
+        const int k = kc / NCK, c = kc % NCK;
         if (c < 10) return v[k * 10 + c];
+        if (PATH && c >= 12) return (c == 12) ? v[k * 10 + 1] + hc[k * 2] * v[k * 10 + 2] : -v[k * 10 + 1] + hc[k * 2 + 1] * v[k * 10 + 2];
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < 10; j++) acc = fma(a.CD[(k * 2 + c - 10) * 10 + j], v[k * 10 + j], acc);
@@ -358,7 +390,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     for (it = 0;; it++) {
 /*@S:1*/
         // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
-        for (int e = lane; e < NS * 12; e += 64) cf[e] = 0.0;
+        for (int e = lane; e < NS * NCK; e += 64) cf[e] = 0.0;
         WSYNC();
         double mu_acc = 0.0, res_gs = 0.0;
         res_d = 0.0; res_m = 0.0;
@@ -389,11 +421,15 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 #pragma unroll
             for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
             if (k < N) {
-                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
-                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
+                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * NCK + 10], acc);
+                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * NCK + 11], acc);
             }
             if (j < 8) acc -= pi[k * 8 + j];
-            acc -= cf[k * 12 + j];
+            acc -= cf[k * NCK + j];
+            if (PATH && (j == 1 || j == 2)) {
+                const double l12 = cf[k * NCK + 12], l13 = cf[k * NCK + 13];
+                acc -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
+            }
             gt[e] = acc;
         }
 /*@S:2*/
@@ -442,7 +478,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         for (int pass = 0; pass < 2; pass++) {
 /*@S:4*/
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
-            for (int e = lane; e < NS * 12; e += 64) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
+            for (int e = lane; e < NS * NCK; e += 64) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
             WSYNC();
             const double mu_t = fmax(sigma * mu, mu_floor);
 #pragma unroll
@@ -475,10 +511,14 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             WSYNC();
             for (int e = lane; e < NS * 10; e += 64) {
                 const int k = e / 10, j = e % 10;
-                double acc = gt[e] + cf[k * 12 + j];
+                double acc = gt[e] + cf[k * NCK + j];
                 if (k < N) {
-                    acc = fma(a.CD[(k * 2 + 0) * 10 + j], cf[k * 12 + 10], acc);
-                    acc = fma(a.CD[(k * 2 + 1) * 10 + j], cf[k * 12 + 11], acc);
+                    acc = fma(a.CD[(k * 2 + 0) * 10 + j], cf[k * NCK + 10], acc);
+                    acc = fma(a.CD[(k * 2 + 1) * 10 + j], cf[k * NCK + 11], acc);
+                }
+                if (PATH && (j == 1 || j == 2)) {
+                    const double c12 = cf[k * NCK + 12], c13 = cf[k * NCK + 13];
+                    acc += (j == 1) ? c12 - c13 : hc[k * 2] * c12 + hc[k * 2 + 1] * c13;
                 }
                 gt[e] = acc;        // pass 1 adds its increment on top of the predictor's gradient
             }
@@ -490,13 +530,19 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 {   // terminal stage
                     const int i = lane >> 3, j = lane & 7;
                     double v = a.Hs[(N * 10 + i) * 10 + j];
-                    if (i == j) v += gam[N * 12 + i];
+                    if (i == j) v += gam[N * NCK + i];
+                    if (PATH && (i == 1 || i == 2) && (j == 1 || j == 2)) {
+                        const double g12 = gam[N * NCK + 12], g13 = gam[N * NCK + 13], a0 = hc[N * 2], a1 = hc[N * 2 + 1];
+                        v += (i == 1 && j == 1) ? g12 + g13 : (i == 2 && j == 2) ? g12 * a0 * a0 + g13 * a1 * a1 : g12 * a0 - g13 * a1;
+                    }
                     Pn[lane] = v;
                     Pg[(size_t)N * 64 + lane] = v;
                 }
                 // this lane's entry of the stage Hessian / general rows, prefetched one stage ahead
                 int gi = 0, gj = 0;
                 if (lane < 55) sym10_ij(lane, gi, gj);
+                // entries of G the track rows touch: (n,n) -> 1, (n,psi) -> 2, (psi,psi) -> 3
+                const int hsel = (lane < 55 && gi == 1 && gj == 1) ? 1 : (lane < 55 && gi + gj == 3 && gi * gj == 2) ? 2 : (lane < 55 && gi == 2 && gj == 2) ? 3 : 0;
                 const int ci = (gi < 8) ? gi : 64 + (gi - 8), si = (gi < 8) ? 8 : 2;      // column gi of [A B] in a record
                 double regH = a.Hs[((N - 1) * 10 + gi) * 10 + gj];
                 double rc0i = a.CD[((N - 1) * 2 + 0) * 10 + gi], rc0j = a.CD[((N - 1) * 2 + 0) * 10 + gj];
@@ -529,9 +575,13 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     // G = H~ + [A B]' W  (upper triangle, 55 entries)
                     if (lane < 55) {
                         double acc = Hk;
-                        if (gi == gj) acc += gam[k * 12 + gi];
-                        acc = fma(gam[k * 12 + 10] * c0i, c0j, acc);
-                        acc = fma(gam[k * 12 + 11] * c1i, c1j, acc);
+                        if (gi == gj) acc += gam[k * NCK + gi];
+                        acc = fma(gam[k * NCK + 10] * c0i, c0j, acc);
+                        acc = fma(gam[k * NCK + 11] * c1i, c1j, acc);
+                        if (PATH && hsel) {
+                            const double g12 = gam[k * NCK + 12], g13 = gam[k * NCK + 13], a0 = hc[k * 2], a1 = hc[k * 2 + 1];
+                            acc += (hsel == 1) ? g12 + g13 : (hsel == 2) ? g12 * a0 - g13 * a1 : g12 * a0 * a0 + g13 * a1 * a1;
+                        }
 #pragma unroll
                         for (int l = 0; l < 8; l++) acc = fma(AB[ci + l * si], Ws[l * 10 + gj], acc);
                         Gs[gi * 10 + gj] = acc;
@@ -741,7 +791,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     }
     double *xw = a.x + (size_t)b * NS * 8, *uw = a.u + (size_t)b * N * 2;
     if (NSOFT > 0) {        // slacks of a failed instance read 0; an all-hard table never touches the array
-        for (int e = lane; e < NS * 24; e += 64) slkb[e] = 0.0;
+        for (int e = lane; e < NS * 28; e += 64) slkb[e] = 0.0;
     }
     if (st == 0) {
         for (int e = lane; e < NS * 10; e += 64) {
@@ -750,15 +800,15 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             else if (k < N) uw[k * 2 + j - 8] += z[e];
         }
         for (int e = lane; e < NS * 8; e += 64) pib[e] = (e < 8) ? 0.0 : pi[e];
-        for (int e = lane; e < NS * 24; e += 64) lamb[e] = 0.0;
+        for (int e = lane; e < NS * 28; e += 64) lamb[e] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
-            const int k = s_kc[r] / 12, c = s_kc[r] % 12;
-            if (fin(s_dl[r])) lamb[k * 24 + c] = lam_l[r];
-            if (fin(s_du[r])) lamb[k * 24 + 12 + c] = lam_u[r];
-            if (IS_SOFT(r)) slkb[k * 24 + (fin(s_dl[r]) ? c : 12 + c)] = so_s[r < NSOFT ? r : 0];
+            const int k = s_kc[r] / NCK, c = s_kc[r] % NCK;
+            if (fin(s_dl[r])) lamb[k * 28 + c] = lam_l[r];
+            if (fin(s_du[r])) lamb[k * 28 + 14 + c] = lam_u[r];
+            if (IS_SOFT(r)) slkb[k * 28 + (fin(s_dl[r]) ? c : 14 + c)] = so_s[r < NSOFT ? r : 0];
         }
     }
     __syncthreads();
@@ -778,20 +828,28 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
     a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M; a.Mt = h->q_Mt;
     const int N = h->N, NS = h->NS;
-    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 12 + 12 + 10) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
+    const int nck = h->path_on ? 14 : 12;
+    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
     if (lds > 160 * 1024) return 1;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
+    a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
     const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
-#define LAUNCH_QP(NS_, NO_)                                                                                              \
+#define LAUNCH_QP(NS_, NO_, PT_)                                                                                         \
     do {                                                                                                                 \
-        (void)hipFuncSetAttribute((const void *)k_qp_wave<NS_, NO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_qp_wave<NS_, NO_>), dim3(h->B), dim3(64), lds, h->stream, a);                              \
+        (void)hipFuncSetAttribute((const void *)k_qp_wave<NS_, NO_, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_qp_wave<NS_, NO_, PT_>), dim3(h->B), dim3(64), lds, h->stream, a);                         \
     } while (0)
-    if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0);
-    else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0);
-    else if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2);
-    else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4);
-    else return 2;
+    if (!h->path_on) {
+        if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0, 0);
+        else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0, 0);
+        else if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 0);
+        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 0);
+        else return 2;
+    } else {
+        if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 1);
+        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 1);
+        else return 2;
+    }
 #undef LAUNCH_QP
     return 0;
 }

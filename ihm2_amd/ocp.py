@@ -13,7 +13,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .constants import NG, NU, NX, NY, t_delta, t_T
+from .constants import NC, NG, NH, NLAM, NU, NX, NY, car_length, car_width, t_delta, t_T
 
 INF = float("inf")
 
@@ -56,6 +56,11 @@ class AcadosModel:
     nx: int = NX
     nu: int = NU
     np_: int = 3000
+    # nonlinear path constraints h(x) of old/generate_acaods_interface.py:191-212: None, or "track" for the two
+    # track-boundary rows (right, left) at every stage and at the terminal stage (con_h_expr / con_h_expr_e there)
+    con_h_expr: str | None = None
+    car_length: float = car_length
+    car_width: float = car_width
 
     @property
     def model_id(self) -> int:
@@ -105,7 +110,8 @@ class AcadosOcpCost:
     Vx_e: np.ndarray = field(default_factory=lambda: np.eye(NX))
     yref: np.ndarray = field(default_factory=lambda: np.ones(NY))
     yref_e: np.ndarray = field(default_factory=lambda: np.ones(NX))
-    # slack penalties, one entry per soft constraint in the order [sbx..., sg...] (acados: zl s + 1/2 Zl s^2 ...)
+    # slack penalties, one entry per soft constraint in the order [sbx..., sg..., sh...] (acados: zl s + 1/2 Zl s^2 ...);
+    # terminal: [sbx_e..., sh_e...]
     zl: np.ndarray = field(default_factory=lambda: np.zeros(0))
     zu: np.ndarray = field(default_factory=lambda: np.zeros(0))
     Zl: np.ndarray = field(default_factory=lambda: np.zeros(0))
@@ -136,6 +142,13 @@ class AcadosOcpConstraints:
     idxsbx: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
     idxsbx_e: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
     idxsg: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    # nonlinear rows lh <= h(x) <= uh (model.con_h_expr); the reference writes -1e3 for "no lower bound"
+    lh: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    uh: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    lh_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    uh_e: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    idxsh: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
+    idxsh_e: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=int))
 
 
 @dataclass
@@ -261,8 +274,13 @@ class OcpData:
     nlp_solver_type: str = "SQP_RTI"
     nlp_solver_max_iter: int = 1
     nlp_tol: float = 1e-6
-    soft_z: np.ndarray | None = None   # (N+1,24) linear slack penalty per one-sided constraint (12 lower, 12 upper)
-    soft_Z: np.ndarray | None = None   # (N+1,24) quadratic slack penalty; < 0 = hard side
+    soft_z: np.ndarray | None = None   # (N+1,28) linear slack penalty per one-sided constraint (14 lower, 14 upper)
+    soft_Z: np.ndarray | None = None   # (N+1,28) quadratic slack penalty; < 0 = hard side
+    path_on: int = 0                   # track-boundary rows h (stages 1..N)
+    car_L: float = car_length
+    car_W: float = car_width
+    lh: np.ndarray = field(default_factory=lambda: np.full(NH, -INF))
+    uh: np.ndarray = field(default_factory=lambda: np.full(NH, INF))
 
     @staticmethod
     def from_ocp(ocp: AcadosOcp) -> "OcpData":
@@ -304,27 +322,45 @@ class OcpData:
         # soft sides: slot rows 0..7 state boxes, 8..9 input boxes, 10..11 general rows
         soft_z = soft_Z = None
         cost = ocp.cost
-        nsbx, nsg, nsbx_e = len(c.idxsbx), len(c.idxsg), len(c.idxsbx_e)
-        if nsbx + nsg + nsbx_e > 0:
-            soft_z = np.zeros((N + 1, 24)); soft_Z = np.full((N + 1, 24), -1.0)
-            if len(cost.zl) != nsbx + nsg or len(cost.Zl) != nsbx + nsg or len(cost.zu) != nsbx + nsg or len(cost.Zu) != nsbx + nsg:
-                raise ValueError("cost.zl/zu/Zl/Zu need one entry per soft constraint [sbx..., sg...]")
-            if len(cost.zl_e) != nsbx_e or len(cost.Zl_e) != nsbx_e or len(cost.zu_e) != nsbx_e or len(cost.Zu_e) != nsbx_e:
-                raise ValueError("cost.zl_e/zu_e/Zl_e/Zu_e need one entry per terminal soft bound")
+        # nonlinear track rows: the same two rows at the stages and at the terminal stage
+        path_on, lh, uh = 0, np.full(NH, -INF), np.full(NH, INF)
+        if ocp.model.con_h_expr is not None:
+            if ocp.model.con_h_expr != "track":
+                raise ValueError("con_h_expr must be None or 'track'")
+            lh, uh = np.asarray(c.lh, dtype=float), np.asarray(c.uh, dtype=float)
+            if lh.shape != (NH,) or uh.shape != (NH,):
+                raise ValueError(f"lh, uh need {NH} entries (right, left track row)")
+            if not (np.array_equal(lh, np.asarray(c.lh_e, dtype=float)) and np.array_equal(uh, np.asarray(c.uh_e, dtype=float))):
+                raise ValueError("lh_e, uh_e must equal lh, uh (old/generate_acaods_interface.py:411-449)")
+            path_on = 1
+        elif len(c.lh) or len(c.idxsh) or len(c.idxsh_e):
+            raise ValueError("lh/uh/idxsh given but model.con_h_expr is None")
+        nsbx, nsg, nsh, nsbx_e, nsh_e = len(c.idxsbx), len(c.idxsg), len(c.idxsh), len(c.idxsbx_e), len(c.idxsh_e)
+        if nsbx + nsg + nsh + nsbx_e + nsh_e > 0:
+            ns, ns_e = nsbx + nsg + nsh, nsbx_e + nsh_e
+            soft_z = np.zeros((N + 1, NLAM)); soft_Z = np.full((N + 1, NLAM), -1.0)
+            if len(cost.zl) != ns or len(cost.Zl) != ns or len(cost.zu) != ns or len(cost.Zu) != ns:
+                raise ValueError("cost.zl/zu/Zl/Zu need one entry per soft constraint [sbx..., sg..., sh...]")
+            if len(cost.zl_e) != ns_e or len(cost.Zl_e) != ns_e or len(cost.zu_e) != ns_e or len(cost.Zu_e) != ns_e:
+                raise ValueError("cost.zl_e/zu_e/Zl_e/Zu_e need one entry per terminal soft constraint [sbx_e..., sh_e...]")
+
+            def put(stages, row, j, e=""):
+                soft_z[stages, row], soft_Z[stages, row] = getattr(cost, "zl" + e)[j], getattr(cost, "Zl" + e)[j]
+                soft_z[stages, NC + row], soft_Z[stages, NC + row] = getattr(cost, "zu" + e)[j], getattr(cost, "Zu" + e)[j]
+
             for j, pos in enumerate(np.asarray(c.idxsbx, dtype=int)):
-                row = int(idx[pos])
-                soft_z[1:N, row], soft_Z[1:N, row] = cost.zl[j], cost.Zl[j]
-                soft_z[1:N, 12 + row], soft_Z[1:N, 12 + row] = cost.zu[j], cost.Zu[j]
+                put(slice(1, N), int(idx[pos]), j)
             for j, pos in enumerate(np.asarray(c.idxsg, dtype=int)):
-                row = 10 + int(pos)
-                soft_z[:N, row], soft_Z[:N, row] = cost.zl[nsbx + j], cost.Zl[nsbx + j]
-                soft_z[:N, 12 + row], soft_Z[:N, 12 + row] = cost.zu[nsbx + j], cost.Zu[nsbx + j]
+                put(slice(0, N), 10 + int(pos), nsbx + j)
+            for j, pos in enumerate(np.asarray(c.idxsh, dtype=int)):
+                put(slice(1, N), 12 + int(pos), nsbx + nsg + j)
             for j, pos in enumerate(np.asarray(c.idxsbx_e, dtype=int)):
-                row = int(idxe[pos])
-                soft_z[N, row], soft_Z[N, row] = cost.zl_e[j], cost.Zl_e[j]
-                soft_z[N, 12 + row], soft_Z[N, 12 + row] = cost.zu_e[j], cost.Zu_e[j]
+                put(N, int(idxe[pos]), j, "_e")
+            for j, pos in enumerate(np.asarray(c.idxsh_e, dtype=int)):
+                put(N, 12 + int(pos), nsbx_e + j, "_e")
         return OcpData(
-            soft_z=soft_z, soft_Z=soft_Z,
+            soft_z=soft_z, soft_Z=soft_Z, path_on=path_on, car_L=float(ocp.model.car_length), car_W=float(ocp.model.car_width),
+            lh=lh, uh=uh,
             N=N, M=int(o.sim_method_num_steps), dt=dt, model=ocp.model.model_id,
             integrator=INTEG_RK4,
             cost_scale_stage=dt if o.cost_scale_stage is None else float(o.cost_scale_stage),
@@ -337,7 +373,7 @@ class OcpData:
             nlp_solver_max_iter=int(o.nlp_solver_max_iter), nlp_tol=float(o.nlp_tol),
         )
 
-    def as_dict(self, s_ref, kappa_ref) -> dict:
+    def as_dict(self, s_ref, kappa_ref, track_widths=None) -> dict:
         """Plain description (arrays + scalars) incl. the track tables (used by the test suite to describe the same problem to its CPU checker)."""
         d = {k: getattr(self, k) for k in (
             "N", "M", "dt", "model", "integrator", "cost_scale_stage", "W", "W_e", "lbx", "ubx", "lbu", "ubu",
@@ -345,6 +381,11 @@ class OcpData:
         d["soft_z"], d["soft_Z"] = self.soft_z, self.soft_Z
         d["s_ref"] = np.atleast_2d(np.asarray(s_ref, dtype=float))
         d["kappa_ref"] = np.atleast_2d(np.asarray(kappa_ref, dtype=float))
+        d["path_on"], d["car_L"], d["car_W"], d["lh"], d["uh"] = self.path_on, self.car_L, self.car_W, self.lh, self.uh
+        if self.path_on:
+            if track_widths is None:
+                raise ValueError("track rows need track_widths (ntracks, 2) = (right, left)")
+            d["widths"] = np.atleast_2d(np.asarray(track_widths, dtype=float))
         return d
 
 

@@ -21,10 +21,9 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .constants import NG, NU, NX, NY
+from .constants import NG, NLAM, NU, NX, NY
 from .ocp import AcadosOcp, AcadosOcpOptions, OcpData
 
-NLAM = 24
 _SOLVER_TYPE = {"SQP_RTI": 0, "SQP": 1}
 
 
@@ -42,7 +41,7 @@ def _ptr(a):
 class BatchedOcpSolver:
     """B independent instances of the bicycle NMPC on one MI355X."""
 
-    def __init__(self, ocp: AcadosOcp, batch_size: int, s_ref, kappa_ref, track_id=None, device: int = 0):
+    def __init__(self, ocp: AcadosOcp, batch_size: int, s_ref, kappa_ref, track_id=None, device: int = 0, track_widths=None):
         self.lib = _lib.load()
         self.ocp = ocp
         self.data: OcpData = ocp.flatten()
@@ -60,6 +59,7 @@ class BatchedOcpSolver:
         self._h = C.c_void_p()
         _lib.check(self.lib.ihm2mpc_create(C.byref(cfg), C.byref(self._h)))
         self._s_ref, self._kappa_ref = s_ref.copy(), kappa_ref.copy()
+        self._track_widths = None if track_widths is None else np.atleast_2d(_f64(track_widths))
         self._push_tracks()
         self.set_track_id(np.zeros(self.B, dtype=np.int32) if track_id is None else track_id)
         self._push_weights()
@@ -98,7 +98,19 @@ class BatchedOcpSolver:
         d = self.data
         arrs = [_f64(getattr(d, n)) for n in ("lbx", "ubx", "lbu", "ubu", "C", "D", "lg", "ug")]
         _lib.check(self.lib.ihm2mpc_set_bounds(self._h, *[_ptr(a) for a in arrs]))
+        self._push_path()
         self._push_soft()
+
+    def _push_path(self):
+        d = self.data
+        if not d.path_on:
+            _lib.check(self.lib.ihm2mpc_set_path_constraints(self._h, 0, 0.0, 0.0, None, None, None))
+            return
+        if self._track_widths is None or self._track_widths.shape != (self.ntracks, 2):
+            raise ValueError(f"the track rows (model.con_h_expr) need track_widths of shape ({self.ntracks}, 2) = (right, left)")
+        lh, uh = _f64(d.lh, (2,), "lh"), _f64(d.uh, (2,), "uh")
+        _lib.check(self.lib.ihm2mpc_set_path_constraints(self._h, 1, float(d.car_L), float(d.car_W), _ptr(self._track_widths),
+                                                         _ptr(lh), _ptr(uh)))
 
     def _push_soft(self):
         d = self.data
@@ -109,7 +121,7 @@ class BatchedOcpSolver:
         _lib.check(self.lib.ihm2mpc_set_soft(self._h, _ptr(z), _ptr(Z)))
 
     def set_soft(self, soft_z=None, soft_Z=None):
-        """Soft constraint sides, ``(N+1, 24)`` each (12 lower then 12 upper; ``soft_Z < 0`` = hard); ``None`` = all hard."""
+        """Soft constraint sides, ``(N+1, 28)`` each (14 lower then 14 upper; ``soft_Z < 0`` = hard); ``None`` = all hard."""
         self.data.soft_z = None if soft_z is None else np.asarray(soft_z, dtype=np.float64)
         self.data.soft_Z = None if soft_Z is None else np.asarray(soft_Z, dtype=np.float64)
         self._push_soft()
@@ -210,7 +222,7 @@ class BatchedOcpSolver:
         return pi, lam
 
     def get_slacks(self):
-        """Slack of each soft constraint side after the last QP, ``(B, N+1, 24)`` (0 for hard sides)."""
+        """Slack of each soft constraint side after the last QP, ``(B, N+1, 28)`` (0 for hard sides)."""
         return self._get(self.lib.ihm2mpc_get_slacks, (self.B, self.N + 1, NLAM))
 
     def get_status(self):

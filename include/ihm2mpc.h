@@ -46,7 +46,7 @@ extern "C" {
 #define IHM2MPC_NY 12
 #define IHM2MPC_NYE 8
 #define IHM2MPC_NG 2
-#define IHM2MPC_NLAM 24 /* multipliers per stage: lower (8 bx, 2 bu, 2 g) then upper (8, 2, 2) */
+#define IHM2MPC_NLAM 28 /* multipliers per stage: lower (8 bx, 2 bu, 2 g, 2 h) then upper (8, 2, 2, 2) */
 #define IHM2MPC_NMAX 128
 
 #define IHM2MPC_MODEL_FKIN6 0 /* python/models.py:232-307 */
@@ -94,10 +94,19 @@ int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, 
                        const double *ubu, const double *C, const double *D, const double *lg,
                        const double *ug);
 /* SOFT constraint sides (AcadosOcpConstraints idxsbx / idxsbx_e / idxsg with AcadosOcpCost zl, zu, Zl, Zu --
- * declared by the reference's OCP class, python/mpc.py:58-90 uses hard sides only): soft_z, soft_Z (N+1,24) per
- * one-sided constraint, 12 lower sides [x(8) u(2) g(2)] then 12 upper sides.  A side with soft_Z >= 0 carries a
+ * declared by the reference's OCP class, python/mpc.py:58-90 uses hard sides only): soft_z, soft_Z (N+1,28) per
+ * one-sided constraint, 14 lower sides [x(8) u(2) g(2) h(2)] then 14 upper sides.  A side with soft_Z >= 0 carries a
  * slack s >= 0 with cost soft_z*s + 1/2*soft_Z*s^2; soft_Z < 0 = hard.  NULL, NULL = all hard (the default). */
 int ihm2mpc_set_soft(ihm2mpc_handle *h, const double *soft_z, const double *soft_Z);
+/* Nonlinear track-boundary rows (model.con_h_expr / con_h_expr_e of old/generate_acaods_interface.py:191-212), rows 12
+ * and 13 of the stages 1..N:
+ *     h_R = n - 1/2 L sin|psi| + 1/2 W cos(psi) - w_R ,   h_L = -n + 1/2 L sin|psi| + 1/2 W cos(psi) - w_L ,
+ * lh <= h <= uh (2 entries each; |bound| >= 1e20 = absent; the reference writes lh = -1e3, uh = 0, :411-449), linearised at
+ * the iterate by every RTI step.  L, W = car length / width (python/constants.py:57-58); widths (ntracks,2) = (w_R, w_L),
+ * constant along a track as the reference's motion plan tiles them (python/motion_planning.py:385-386).
+ * enable = 0 removes the rows (the other arguments are then ignored and may be NULL). */
+int ihm2mpc_set_path_constraints(ihm2mpc_handle *h, int32_t enable, double car_length, double car_width,
+                                 const double *widths, const double *lh, const double *uh);
 
 /* ---- per-instance data ---- */
 int ihm2mpc_set_x0(ihm2mpc_handle *h, const double *x0);         /* (B,8) */
@@ -105,7 +114,7 @@ int ihm2mpc_set_x(ihm2mpc_handle *h, const double *x);           /* (B,N+1,8) */
 int ihm2mpc_set_u(ihm2mpc_handle *h, const double *u);           /* (B,N,2) */
 int ihm2mpc_set_yref(ihm2mpc_handle *h, const double *yref);     /* (B,N,12) */
 int ihm2mpc_set_yref_e(ihm2mpc_handle *h, const double *yref_e); /* (B,8) */
-int ihm2mpc_set_multipliers(ihm2mpc_handle *h, const double *pi, const double *lam); /* (B,N+1,8), (B,N+1,24); NULL = zero */
+int ihm2mpc_set_multipliers(ihm2mpc_handle *h, const double *pi, const double *lam); /* (B,N+1,8), (B,N+1,28); NULL = zero */
 
 /* one stage of one instance (the AcadosOcpSolver.set/get call shape); field is one of
  * "x","u","yref","yref_e","lbx","ubx" (stage 0 only: both set x0),"pi","lam" */
@@ -133,7 +142,7 @@ int ihm2mpc_get_status(ihm2mpc_handle *h, int32_t *status);     /* (B) */
 int ihm2mpc_get_qp_iter(ihm2mpc_handle *h, int32_t *qp_iter);   /* (B) */
 int ihm2mpc_get_residuals(ihm2mpc_handle *h, double *res);      /* (B,4): stat, eq, ineq, comp */
 int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam);
-int ihm2mpc_get_slacks(ihm2mpc_handle *h, double *sl);         /* (B,N+1,24) slack of each soft side after the last QP */
+int ihm2mpc_get_slacks(ihm2mpc_handle *h, double *sl);         /* (B,N+1,28) slack of each soft side after the last QP */
 /* milliseconds of the last solve(): [0] total, [1] linearize, [2] qp+update (HIP events) */
 int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n);
 

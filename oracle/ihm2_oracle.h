@@ -31,8 +31,9 @@ extern "C" {
 #define ORC_NY 12
 #define ORC_NYE 8
 #define ORC_NG 2
-/* one-sided inequalities per stage: lower (8 bx, 2 bu, 2 g) then upper (8, 2, 2) */
-#define ORC_NC 12
+#define ORC_NH 2
+/* one-sided inequalities per stage: lower (8 bx, 2 bu, 2 g, 2 h) then upper (8, 2, 2, 2) */
+#define ORC_NC 14
 #define ORC_NMAX 128
 
 enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1 };
@@ -62,10 +63,18 @@ typedef struct {
     const double *D;   /* (N, 2, 2) */
     const double *lg;  /* (N, 2) */
     const double *ug;  /* (N, 2) */
-    /* soft constraint sides (old/generate_acaods_interface.py:380-395): (N+1,24) per one-sided constraint,
-     * 12 lower then 12 upper; soft_Z < 0 = hard; NULL = all hard */
+    /* soft constraint sides (old/generate_acaods_interface.py:380-395): (N+1,28) per one-sided constraint,
+     * 14 lower then 14 upper; soft_Z < 0 = hard; NULL = all hard */
     const double *soft_z;
     const double *soft_Z;
+    /* nonlinear track-boundary rows (old/generate_acaods_interface.py:191-212), stages 1..N:
+     *   h_R = n - 1/2 L sin|psi| + 1/2 W cos(psi) - w_R ,  h_L = -n + 1/2 L sin|psi| + 1/2 W cos(psi) - w_L
+     * with lh <= h <= uh (|bound| >= 1e20 = absent); widths (ntracks,2) = (w_R, w_L), constant along a track as in
+     * python/motion_planning.py:385-386; path_on = 0 disables the rows */
+    int path_on;
+    double car_L, car_W;
+    const double *widths;
+    double lh[ORC_NH], uh[ORC_NH];
     /* interior-point options */
     int ipm_iter_max;
     double ipm_tol;  /* abs inf-norm tolerance on all four residual groups */
@@ -93,8 +102,8 @@ void orc_rk4(int model, int integrator, const double *x, const double *u, const 
 
 /* --- stage-wise QP by Riccati-based primal-dual interior point ---
  * H (N+1,10,10), g (N+1,10), A (N,8,8), Bm (N,8,2), b (N,8), dx0 (8),
- * R (N+1, 12, 10) constraint rows, dl/du (N+1, 12) (+-inf = absent)
- * out: dz (N+1,10), pi (N+1,8), lam (N+1,24) [12 lower then 12 upper], t (N+1,24)
+ * R (N+1, 14, 10) constraint rows, dl/du (N+1, 14) (+-inf = absent)
+ * out: dz (N+1,10), pi (N+1,8), lam (N+1,28) [14 lower then 14 upper], t (N+1,28)
  * stats[0..3] = res_g,res_b,res_d,res_m at exit, stats[4]=mu, stats[5..6] = scales sg, sb (stats has 8 slots)
  * tolerances are relative: res_g,res_m <= tol*sg, res_b,res_d <= tol*sb; mu0 is a factor on sg.
  * returns 0 converged, 1 max-iter but within 1e4*tol, 2 min step, 3 NaN, 4 max-iter and not converged */
@@ -103,8 +112,8 @@ int orc_qp_solve(int N, const double *H, const double *g, const double *A, const
                  const double *du, int iter_max, double tol, double mu0, double tau0, double *dz,
                  double *pi, double *lam, double *t, double *stats, int *iters);
 
-/* same with SOFT constraint sides: soft_z, soft_Z (N+1,24) per one-sided constraint (12 lower then 12 upper);
- * a side with soft_Z >= 0 carries a slack s >= 0 with cost soft_z s + 1/2 soft_Z s^2; sl (N+1,24): slack values out */
+/* same with SOFT constraint sides: soft_z, soft_Z (N+1,28) per one-sided constraint (12 lower then 12 upper);
+ * a side with soft_Z >= 0 carries a slack s >= 0 with cost soft_z s + 1/2 soft_Z s^2; sl (N+1,28): slack values out */
 int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, const double *Bm,
                       const double *b, const double *dx0, const double *R, const double *dl,
                       const double *du, const double *soft_z, const double *soft_Z, int iter_max, double tol,

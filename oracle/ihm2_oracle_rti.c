@@ -112,7 +112,7 @@ void orc_build_qp(const orc_problem *P, const double *x, const double *u, const 
             /* keep the padded u-block non-singular; it never couples to anything */
             H[(k * NZ + 8) * NZ + 8] = 1.0; H[(k * NZ + 9) * NZ + 9] = 1.0;
         }
-        /* constraints: rows 0..7 state bounds, 8..9 input bounds, 10..11 general rows */
+        /* constraints: rows 0..7 state bounds, 8..9 input bounds, 10..11 general rows, 12..13 track rows */
         for (int c = 0; c < NC; c++) { dl[k * NC + c] = -INFINITY; du[k * NC + c] = INFINITY; }
         if (k >= 1)
             for (int i = 0; i < NX; i++) {
@@ -136,6 +136,21 @@ void orc_build_qp(const orc_problem *P, const double *x, const double *u, const 
                 double lb = P->lg[k * ORC_NG + i], ub = P->ug[k * ORC_NG + i];
                 if (fabs(lb) < INF_BOUND) dl[k * NC + 10 + i] = lb - val;
                 if (fabs(ub) < INF_BOUND) du[k * NC + 10 + i] = ub - val;
+            }
+        }
+        if (P->path_on && k >= 1) {
+            /* h(x) and its gradient in (n, psi); d|psi|/dpsi = sign(psi) with sign(0) = 0 as CasADi differentiates fabs */
+            const double n = xk[1], psi = xk[2], sg = (psi > 0.0) - (psi < 0.0);
+            const double hl = 0.5 * P->car_L, hw = 0.5 * P->car_W;
+            const double foot = -hl * sin(fabs(psi)), lat = hw * cos(psi);
+            const double dfoot = -hl * cos(fabs(psi)) * sg, dlat = -hw * sin(psi);
+            const double hval[ORC_NH] = {n + foot + lat - P->widths[tid * 2 + 0], -n - foot + lat - P->widths[tid * 2 + 1]};
+            const double dn[ORC_NH] = {1.0, -1.0}, dpsi[ORC_NH] = {dfoot + dlat, -dfoot + dlat};
+            for (int i = 0; i < ORC_NH; i++) {
+                R[(k * NC + 12 + i) * NZ + 1] = dn[i];
+                R[(k * NC + 12 + i) * NZ + 2] = dpsi[i];
+                if (fabs(P->lh[i]) < INF_BOUND) dl[k * NC + 12 + i] = P->lh[i] - hval[i];
+                if (fabs(P->uh[i]) < INF_BOUND) du[k * NC + 12 + i] = P->uh[i] - hval[i];
             }
         }
     }

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libihm2_oracle.so")
-NX, NU, NZ, NY, NC, NG = 8, 2, 10, 12, 12, 2
+NX, NU, NZ, NY, NC, NG, NH = 8, 2, 10, 12, 14, 2, 2
 MODEL_FKIN6, MODEL_FDYN6 = 0, 1
 INTEG_RK4 = 0
 
@@ -28,6 +28,8 @@ class _Problem(C.Structure):
         ("ntracks", C.c_int), ("nknots", C.c_int), ("s_ref", _dp), ("kappa_ref", _dp),
         ("W", _dp), ("W_e", _dp), ("lbx", _dp), ("ubx", _dp), ("lbu", _dp), ("ubu", _dp),
         ("C", _dp), ("D", _dp), ("lg", _dp), ("ug", _dp), ("soft_z", _dp), ("soft_Z", _dp),
+        ("path_on", C.c_int), ("car_L", C.c_double), ("car_W", C.c_double), ("widths", _dp),
+        ("lh", C.c_double * NH), ("uh", C.c_double * NH),
         ("ipm_iter_max", C.c_int), ("ipm_tol", C.c_double), ("ipm_mu0", C.c_double), ("ipm_tau0", C.c_double),
     ]
 
@@ -145,6 +147,15 @@ class OracleProblem:
                 assert a.shape == (self.N + 1, 2 * NC)
                 self._keep[name] = a
                 setattr(p, name, ptr)
+        p.path_on = int(desc.get("path_on", 0))
+        if p.path_on:
+            p.car_L, p.car_W = float(desc["car_L"]), float(desc["car_W"])
+            w, ptr = _d(np.atleast_2d(desc["widths"]))
+            assert w.shape == (p.ntracks, 2)
+            self._keep["widths"] = w
+            p.widths = ptr
+            for i in range(NH):
+                p.lh[i] = float(desc["lh"][i]); p.uh[i] = float(desc["uh"][i])
         N = self.N
         assert self._keep["W"].shape == (N, NY, NY) and self._keep["lbx"].shape == (N + 1, NX)
         assert self._keep["C"].shape == (N, NG, NX) and self._keep["D"].shape == (N, NG, NU)

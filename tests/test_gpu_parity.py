@@ -310,7 +310,7 @@ def test_soft_rti_step_matches_oracle(setup_soft):
     # the soft n-bound is violated by the solution exactly by its slack (complementary sides)
     n_pred = xg[ok][:, 1:, 1]
     over = np.maximum(np.abs(n_pred) - 0.3, 0.0)
-    used = np.maximum(sl[ok][:, 1:, 1], sl[ok][:, 1:, 13])
+    used = np.maximum(sl[ok][:, 1:, 1], sl[ok][:, 1:, 14 + 1])
     assert np.max(over - used) < 1e-6
 
 
@@ -325,3 +325,63 @@ def test_soft_sides_can_be_switched_off_again(setup_soft, track):
     s.set_x0(setup_soft["x0"]); s.init_guess(); s.set_multipliers(None, None)
     st_soft = s.solve()
     assert (st_soft == 0).sum() > (st_hard == 0).sum()       # |n0| > n_max is infeasible with hard sides
+
+
+# ---- nonlinear track-boundary rows h (old/generate_acaods_interface.py:191-212), hard and soft (BASELINE.json configs[2]) ----
+def _path_setup(track, model, soft, B, seed, width):
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    ocp = make_ocp(model=model)
+    ocp.model.con_h_expr = "track"
+    c = ocp.constraints
+    c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+    if soft:        # all h rows soft with L1 + L2 weights 100 / 100 (old/generate_acaods_interface.py:380-395, idxsh = all)
+        c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+        ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+        ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+    w = np.array([[width, width - 0.1]])
+    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, track_widths=w)
+    P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref, track_widths=w))
+    x0 = sample_x0(track, B, seed=seed)
+    if model == "fdyn6":
+        x0[:, 3] = np.linspace(6.0, 14.0, B)
+    solver.set_x0(x0)
+    solver.init_guess()
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref[:, :, 1] = np.where(np.arange(B) % 2 == 0, 1.5, -1.5)[:, None]       # pull the cars onto the boundaries
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0; yref_e[:, 1] = yref[:, 0, 1]
+    solver.set_yref(yref); solver.set_yref_e(yref_e); solver.set_multipliers(None, None)
+    return solver, P, x0, yref, yref_e
+
+
+@pytest.mark.parametrize("model,soft,width", [("fkin6", False, 1.6), ("fkin6", True, 1.2), ("fdyn6", True, 1.2)])
+def test_track_rows_rti_steps_match_oracle(track, model, soft, width):
+    B = 66
+    s, P, x0, yref, yref_e = _path_setup(track, model, soft, B, 99, width)
+    x, u = s.get_x(), s.get_u()
+    pi = lam = None
+    n_active = 0
+    for it in range(3):                     # three SQP iterations on the frozen problem, multipliers carried along
+        status = s.solve()
+        out = P.rti_step(x, u, x0, yref, yref_e, pi=pi, lam=lam)
+        pi, lam = out["pi"], out["lam"]
+        np.testing.assert_array_equal(status, out["status"])
+        ok = status == 0
+        np.testing.assert_array_equal(s.get_qp_iter()[ok], out["qp_iter"][ok])
+        xg, ug = s.get_x(), s.get_u()
+        assert _rel(xg[ok], x[ok]) < 1e-6       # tolerance 1e-6 relative (north star: 1e-5)
+        assert _rel(ug[ok], u[ok]) < 1e-6
+        assert _rel(s.get_residuals(), out["res"]) < 1e-7
+        _, lam_g = s.get_multipliers()
+        assert np.max(np.abs(lam_g[ok] - lam[ok])) / (1.0 + np.abs(lam).max()) < 1e-5
+        n_active += int((np.abs(lam[ok][:, :, 14 + 12:14 + 14]) > 1e-3).sum())
+        # keep both sides on the same iterate (differences of 1e-7 would otherwise compound through the non-convex NLP)
+        s.set_x(x); s.set_u(u); s.set_multipliers(pi, lam)
+        if model == "fkin6":
+            assert ok.sum() >= 0.9 * B
+    assert n_active > 0                         # the rows really bind
+    if soft:
+        sl = s.get_slacks()
+        assert np.all(sl[:, :, :12] == 0.0) and np.all(sl[:, 0] == 0.0)
+        assert sl[:, 1:, 14 + 12:].max() > 1e-3     # some footprint is outside the narrow track and pays for it

@@ -7,7 +7,7 @@ from scipy.optimize import minimize
 
 from oracle import oracle as orc
 
-NX, NU, NZ, NC = 8, 2, 10, 12
+NX, NU, NZ, NC = 8, 2, 10, 14
 
 
 def random_qp(rng, N, with_ineq=True):
