@@ -30,9 +30,12 @@ class SimModelVariant(Enum):
     DYN6 = auto()
     KIN6_DYN6 = auto()
     DYN10 = auto()          # not implemented
+    DYN6U = auto()          # DYN6 / KIN6_DYN6 with un-crossed slip angles (named deviation from quirk Q3)
+    KIN6_DYN6U = auto()
 
 
-_PLANT_CODE = {SimModelVariant.KIN6: 0, SimModelVariant.DYN6: 1, SimModelVariant.KIN6_DYN6: -1}
+_PLANT_CODE = {SimModelVariant.KIN6: 0, SimModelVariant.DYN6: 1, SimModelVariant.KIN6_DYN6: -1, SimModelVariant.DYN6U: 2,
+               SimModelVariant.KIN6_DYN6U: -2}
 
 
 @dataclass

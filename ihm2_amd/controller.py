@@ -106,6 +106,8 @@ class IHM2Controller(Controller):
         nlp_solver_max_iter: int = 1,
         terminal_bounds: str = "reference",
         soft_state_bounds: tuple | None = None,
+        track_widths=None,
+        track_rows_penalty: tuple | None = (100.0, 100.0),
     ) -> None:
         self.Nf, self.dt, self.s_target, self.B = Nf, dt, s_target, int(batch_size)
         self.config = Controller.Config(horizon_size=Nf, sampling_time=dt)
@@ -137,6 +139,22 @@ class IHM2Controller(Controller):
             ocp.cost.Zl = ocp.cost.Zu = np.full(nsb, Z_pen)
             ocp.cost.zl_e = ocp.cost.zu_e = np.full(nsb_e, z_pen)
             ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(nsb_e, Z_pen)
+        if track_widths is not None:
+            # the nonlinear track-boundary rows of old/generate_acaods_interface.py:191-212,411-449 (footprint of the car
+            # against the right / left width), soft with L1 + L2 weights (:380-395) unless track_rows_penalty is None
+            model.con_h_expr = "track"
+            c = ocp.constraints
+            c.lh = c.lh_e = np.array([-1e3, -1e3])
+            c.uh = c.uh_e = np.array([0.0, 0.0])
+            if track_rows_penalty is not None:
+                z_pen, Z_pen = (float(v) for v in track_rows_penalty)
+                c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+                for name in ("zl", "zu"):
+                    setattr(ocp.cost, name, np.concatenate([getattr(ocp.cost, name), np.full(2, z_pen)]))
+                    setattr(ocp.cost, name + "_e", np.concatenate([getattr(ocp.cost, name + "_e"), np.full(2, z_pen)]))
+                for name in ("Zl", "Zu"):
+                    setattr(ocp.cost, name, np.concatenate([getattr(ocp.cost, name), np.full(2, Z_pen)]))
+                    setattr(ocp.cost, name + "_e", np.concatenate([getattr(ocp.cost, name + "_e"), np.full(2, Z_pen)]))
         opts = AcadosOcpOptions()                      # python/main.py:227-238, with ERK x M for IRK
         opts.tf = Nf * dt
         opts.nlp_solver_type = nlp_solver_type
@@ -145,7 +163,7 @@ class IHM2Controller(Controller):
         ocp.solver_options = opts
         ocp.cost.W, ocp.cost.W_e = default_weights(q_s, q_n, q_psi, q_v_x, q_v_y, q_r, q_T, q_delta, q_s_f, q_n_f, q_psi_f,
                                                    q_v_x_f, q_v_y_f, q_r_f, q_T_f, q_delta_f, q_T_dot, q_delta_dot)
-        self.solver = BatchedOcpSolver(ocp, self.B, s_ref, kappa_ref, track_id=track_id, device=device)
+        self.solver = BatchedOcpSolver(ocp, self.B, s_ref, kappa_ref, track_id=track_id, device=device, track_widths=track_widths)
         # cold start of the prediction arrays (python/main.py:242-246)
         x_pred = np.zeros((self.B, Nf + 1, NX))
         x_pred[:, :, 0] = -6.0 + np.arange(Nf + 1) * dt

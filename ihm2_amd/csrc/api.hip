@@ -116,7 +116,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     if (cfg->batch < 1) return fail("batch must be >= 1");
     if (cfg->N < 2 || cfg->N > IHM2MPC_NMAX) return fail("N must be in [2, %d]", IHM2MPC_NMAX);
     if (cfg->M < 1) return fail("M must be >= 1");
-    if (cfg->model != IHM2MPC_MODEL_FKIN6 && cfg->model != IHM2MPC_MODEL_FDYN6) return fail("unknown OCP model %d", cfg->model);
+    if (cfg->model < IHM2MPC_MODEL_FKIN6 || cfg->model > IHM2MPC_MODEL_FDYN6U) return fail("unknown OCP model %d", cfg->model);
     if (cfg->ntracks < 1 || cfg->nknots < 2) return fail("need at least one track table with >= 2 knots");
     if (!(cfg->dt > 0.0)) return fail("dt must be positive");
     int ndev = 0;
@@ -589,7 +589,7 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (!x || !u || !x_next) return fail("null argument");
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (model < -1 || model > IHM2MPC_MODEL_FDYN6) return fail("unknown plant model %d", model);
+    if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
     if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
     ihm2_launch_sim(h, model, M_sim, xs, us, xn);
@@ -602,7 +602,7 @@ int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim)
     CHECK_H(h);
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (model < -1 || model > IHM2MPC_MODEL_FDYN6) return fail("unknown plant model %d", model);
+    if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0);
     HIP_TRY(hipGetLastError());
     return 0;

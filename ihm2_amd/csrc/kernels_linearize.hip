@@ -23,7 +23,7 @@ template <int MODEL, int COL>
 __device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const double (&S)[8], double (&Sacc)[8],
                                                double (&dK)[8], double ah, double wh)
 {
-    constexpr unsigned cm = S_COL_MASK[MODEL][COL];
+    constexpr unsigned cm = S_COL_MASK[MODEL ? 1 : 0][COL];
     double dX[8];
 #pragma unroll
     for (int l = 0; l < 8; l++)
@@ -32,10 +32,10 @@ __device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const d
     for (int i = 0; i < 8; i++) {
         if (!((cm >> i) & 1u)) continue;
         double acc = 0.0;
-        if (COL >= 8 && ((JU_MASK[MODEL][i] >> (COL - 8)) & 1u)) acc = J[i][COL];
+        if (COL >= 8 && ((JU_MASK[MODEL ? 1 : 0][i] >> (COL - 8)) & 1u)) acc = J[i][COL];
 #pragma unroll
         for (int l = 0; l < 8; l++)
-            if (((JX_MASK[MODEL][i] & cm) >> l) & 1u) acc = fma(J[i][l], dX[l], acc);
+            if (((JX_MASK[MODEL ? 1 : 0][i] & cm) >> l) & 1u) acc = fma(J[i][l], dX[l], acc);
         dK[i] = acc;
     }
 #pragma unroll
@@ -46,7 +46,7 @@ __device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const d
 template <int MODEL, int COL>
 __device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&dst)[8])
 {
-    constexpr unsigned cm = S_COL_MASK[MODEL][COL];
+    constexpr unsigned cm = S_COL_MASK[MODEL ? 1 : 0][COL];
 #pragma unroll
     for (int i = 0; i < 8; i++)
         if ((cm >> i) & 1u) dst[i] = src[i];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_linearize(
 #pragma unroll
             for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
             if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval<true>(X, u_T, u_d, trk, K, J);
+            else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, K, J);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
 #define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sacc[c], dK[c], ah, wh);
@@ -114,14 +114,14 @@ __global__ __launch_bounds__(64) void k_linearize(
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL][j] >> i) & 1u) ? S[j][i] : 0.0;
+        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL ? 1 : 0][j] >> i) & 1u) ? S[j][i] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL][8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
+        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL ? 1 : 0][8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
         rec[80 + i] = x[i] - xk[8 + i];
     }
 }
 
-// plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 = kin/dyn switch of
+// plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 (-2: with fdyn6u) = kin/dyn switch of
 // python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic)
 __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double dt, int nknots,
                                                  const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double
     if (model < 0) {
         const double beta = atan(k_rwd * tan(x[7]));
         const double v2 = x[3] * x[3] + x[4] * x[4];
-        mdl = (v2 * sin(beta) / k_lR <= 3.0) ? IHM2MPC_MODEL_FKIN6 : IHM2MPC_MODEL_FDYN6;
+        mdl = (v2 * sin(beta) / k_lR <= 3.0) ? IHM2MPC_MODEL_FKIN6 : (model == -2 ? IHM2MPC_MODEL_FDYN6U : IHM2MPC_MODEL_FDYN6);
     }
     const double h = dt / M;
     double J[8][10];
@@ -157,7 +157,8 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double
 #pragma unroll
             for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
             if (mdl == IHM2MPC_MODEL_FKIN6) fkin6_eval<false>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval<false>(X, u_T, u_d, trk, K, J);
+            else if (mdl == IHM2MPC_MODEL_FDYN6U) fdyn6_eval<false, true>(X, u_T, u_d, trk, K, J);
+            else fdyn6_eval<false, false>(X, u_T, u_d, trk, K, J);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
         }
@@ -174,7 +175,10 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
 {
     const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
-    if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
+    if (h->cfg.model == IHM2MPC_MODEL_FDYN6U)
+        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+                           h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
+    else if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
         hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else

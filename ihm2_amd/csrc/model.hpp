@@ -241,7 +241,7 @@ __device__ __forceinline__ T lat_pacejka_t(const T &alpha)
 template <typename T>
 __device__ __forceinline__ T smooth_abs_nonzero_t(const T &v) { return mtanh(v * 10.0) * v + mexp(-(v * v)) * 1e-6; }
 
-template <typename T>
+template <typename T, bool UNCROSSED>
 __device__ inline void fdyn6_forces(const T &v_x, const T &v_y, const T &r, const T &Tq, const T &delta, T &vxd, T &vyd, T &rd)
 {
     const T sd = msin(delta), cd = mcos(delta);
@@ -258,8 +258,10 @@ __device__ inline void fdyn6_forces(const T &v_x, const T &v_y, const T &r, cons
     const T a_FR = matan(v_lat_FR / smooth_abs_nonzero_t(v_lon_FR));
     const T a_RL = matan(v_lat_R / smooth_abs_nonzero_t(v_x_FL));      // v_lon_RL = v_x - hx r
     const T a_RR = matan(v_lat_R / smooth_abs_nonzero_t(v_x_FR));      // v_lon_RR = v_x + hx r
-    // crossed slip angles exactly as models.py:543-546 (quirk Q3); order FL, FR, RL, RR
-    const T glat0 = lat_pacejka_t(a_RR), glat1 = lat_pacejka_t(a_RL), glat2 = lat_pacejka_t(a_FR), glat3 = lat_pacejka_t(a_FL);
+    // crossed slip angles exactly as models.py:543-546 (quirk Q3); order FL, FR, RL, RR.  UNCROSSED (model "fdyn6u") gives every
+    // wheel its own slip angle: the crossed form is open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s)
+    const T glat0 = lat_pacejka_t(UNCROSSED ? a_FL : a_RR), glat1 = lat_pacejka_t(UNCROSSED ? a_FR : a_RL);
+    const T glat2 = lat_pacejka_t(UNCROSSED ? a_RL : a_FR), glat3 = lat_pacejka_t(UNCROSSED ? a_RR : a_FL);
     const T F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
     const T beta = matan(mtan(delta) * k_rwd);
     const T r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
@@ -289,7 +291,7 @@ __device__ inline void fdyn6_forces(const T &v_x, const T &v_y, const T &r, cons
 }
 
 // xdot (and with WITH_JAC the structural non-zeros of its Jacobian, pattern JX_MASK[1] / JU_MASK[1])
-template <bool WITH_JAC>
+template <bool WITH_JAC, bool UNCROSSED>
 __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
 {
     const double n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
@@ -308,7 +310,7 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
     if (WITH_JAC) {
         typedef Dual<5> D5;
         D5 o0, o1, o2;
-        fdyn6_forces<D5>(mk_var<5>(v_x, 0), mk_var<5>(v_y, 1), mk_var<5>(r, 2), mk_var<5>(T, 3), mk_var<5>(delta, 4), o0, o1, o2);
+        fdyn6_forces<D5, UNCROSSED>(mk_var<5>(v_x, 0), mk_var<5>(v_y, 1), mk_var<5>(r, 2), mk_var<5>(T, 3), mk_var<5>(delta, 4), o0, o1, o2);
         f[3] = o0.v; f[4] = o1.v; f[5] = o2.v;
 #pragma unroll
         for (int c = 0; c < 5; c++) { J[3][3 + c] = o0.d[c]; J[4][3 + c] = o1.d[c]; J[5][3 + c] = o2.d[c]; }
@@ -332,7 +334,7 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
         J[7][7] = -1.0 / k_tdelta;
         J[7][9] = 1.0 / k_tdelta;
     } else {
-        fdyn6_forces<double>(v_x, v_y, r, T, delta, f[3], f[4], f[5]);
+        fdyn6_forces<double, UNCROSSED>(v_x, v_y, r, T, delta, f[3], f[4], f[5]);
     }
 }
 

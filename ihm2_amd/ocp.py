@@ -19,7 +19,8 @@ INF = float("inf")
 
 MODEL_FKIN6 = 0
 MODEL_FDYN6 = 1
-_MODEL_IDS = {"fkin6": MODEL_FKIN6, "fdyn6": MODEL_FDYN6}
+MODEL_FDYN6U = 2     # fdyn6 with un-crossed slip angles (include/ihm2mpc.h: IHM2MPC_MODEL_FDYN6U); not in the reference
+_MODEL_IDS = {"fkin6": MODEL_FKIN6, "fdyn6": MODEL_FDYN6, "fdyn6u": MODEL_FDYN6U}
 INTEG_RK4 = 0
 
 
@@ -47,6 +48,12 @@ def fkin6_model(x=None, u=None, p=None):
 def fdyn6_model(xdot=None, x=None, u=None, p=None):
     """Frenet dynamic 4-wheel Pacejka model (implicit in the reference; solved for xdot on device)."""
     return "fdyn6"
+
+
+def fdyn6u_model(xdot=None, x=None, u=None, p=None):
+    """``fdyn6_model`` with every wheel's lateral force on its own slip angle.  The reference crosses them
+    (``python/models.py:543-546``), which makes the model open-loop unstable; this variant is a named deviation."""
+    return "fdyn6u"
 
 
 @dataclass

@@ -51,6 +51,9 @@ extern "C" {
 
 #define IHM2MPC_MODEL_FKIN6 0 /* python/models.py:232-307 */
 #define IHM2MPC_MODEL_FDYN6 1 /* python/models.py:455-606 */
+/* fdyn6 with every wheel's lateral force on its OWN slip angle.  The reference crosses them (F_lat_FL uses alpha_RR ...,
+ * python/models.py:543-546, quirk Q3); as written the model is open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s) */
+#define IHM2MPC_MODEL_FDYN6U 2
 
 #define IHM2MPC_SQP_RTI 0 /* old/generate.py:21 */
 #define IHM2MPC_SQP 1     /* python/main.py:230 */
@@ -157,7 +160,8 @@ int ihm2mpc_get_status_device(ihm2mpc_handle *h, void *dptr);
 /* ---- plant step (closed-loop MiL): x_next = RK4 x M_sim over dt of `model` under u ---- */
 int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const double *x,
                      const double *u, double *x_next); /* host (B,8),(B,2) -> (B,8) */
-/* on device: x0 <- plant(x0, u0 of the last solve); model = -1: kin/dyn switch of python/main.py:482-489 */
+/* on device: x0 <- plant(x0, u0 of the last solve); model = -1: kin/dyn switch of python/main.py:482-489 (-2: the same
+ * switch with IHM2MPC_MODEL_FDYN6U as the dynamic model) */
 int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim);
 int ihm2mpc_get_x0(ihm2mpc_handle *h, double *x0);
 

@@ -36,7 +36,9 @@ extern "C" {
 #define ORC_NC 14
 #define ORC_NMAX 128
 
-enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1 };
+/* FDYN6U: fdyn6 with every wheel's lateral force on its OWN slip angle; the reference crosses them (python/models.py:543-546,
+ * quirk Q3), which makes the model open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s) */
+enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1, ORC_MODEL_FDYN6U = 2 };
 enum { ORC_INTEG_RK4 = 0 };
 
 typedef struct {

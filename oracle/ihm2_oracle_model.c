@@ -143,7 +143,7 @@ static void fkin6_cs(const cplx *x, const cplx *u, const double *s_ref, const do
 }
 
 /* ---- fdyn6 (python/models.py:455-606), explicit form via the 2x2 solve of SURVEY.md C.2 ---- */
-static void fdyn6_cs(const cplx *x, const cplx *u, const double *s_ref, const double *kappa_ref, int nk, cplx *f)
+static void fdyn6_cs(const cplx *x, const cplx *u, const double *s_ref, const double *kappa_ref, int nk, cplx *f, int uncrossed)
 {
     const double rwd = l_R / wheelbase;
     cplx s = x[0], n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
@@ -174,6 +174,10 @@ static void fdyn6_cs(const cplx *x, const cplx *u, const double *s_ref, const do
     /* lateral force per unit F_z, with the crossed indices of :543-546 (quirk Q3) */
     cplx glat[4] = {cs_lat_pacejka(alpha_RR), cs_lat_pacejka(alpha_RL), cs_lat_pacejka(alpha_FR),
                     cs_lat_pacejka(alpha_FL)};
+    if (uncrossed) { /* ORC_MODEL_FDYN6U: every wheel with its own slip angle (named deviation from the reference) */
+        glat[0] = cs_lat_pacejka(alpha_FL); glat[1] = cs_lat_pacejka(alpha_FR);
+        glat[2] = cs_lat_pacejka(alpha_RL); glat[3] = cs_lat_pacejka(alpha_RR);
+    }
     /* longitudinal :549-560 */
     cplx F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * cs_smooth_sgn(v_x);
     cplx beta = cs_atan(rwd * cs_tan(delta));
@@ -225,7 +229,7 @@ static void fdyn6_cs(const cplx *x, const cplx *u, const double *s_ref, const do
 
 static void f_cs(int model, const cplx *x, const cplx *u, const double *s_ref, const double *kappa_ref, int nk, cplx *f)
 {
-    if (model == ORC_MODEL_FDYN6) fdyn6_cs(x, u, s_ref, kappa_ref, nk, f);
+    if (model == ORC_MODEL_FDYN6 || model == ORC_MODEL_FDYN6U) fdyn6_cs(x, u, s_ref, kappa_ref, nk, f, model == ORC_MODEL_FDYN6U);
     else fkin6_cs(x, u, s_ref, kappa_ref, nk, f);
 }
 

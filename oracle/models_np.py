@@ -89,7 +89,7 @@ def fkin6(x, u, s_ref, kappa_ref):
     ])
 
 
-def fdyn6_residual(xdot, x, u, s_ref, kappa_ref):
+def fdyn6_residual(xdot, x, u, s_ref, kappa_ref, uncrossed=False):
     """Implicit residual exactly in the order of python/models.py:574-606."""
     s, n, psi, v_x, v_y, r, T, delta = x
     u_T, u_delta = u
@@ -124,6 +124,9 @@ def fdyn6_residual(xdot, x, u, s_ref, kappa_ref):
     F_lat_FR = F_z_FR * lat_pacejka(alpha_RL)
     F_lat_RL = F_z_RL * lat_pacejka(alpha_FR)
     F_lat_RR = F_z_RR * lat_pacejka(alpha_FL)
+    if uncrossed:       # model "fdyn6u": every wheel with its own slip angle (named deviation from quirk Q3)
+        F_lat_FL, F_lat_FR = F_z_FL * lat_pacejka(alpha_FL), F_z_FR * lat_pacejka(alpha_FR)
+        F_lat_RL, F_lat_RR = F_z_RL * lat_pacejka(alpha_RL), F_z_RR * lat_pacejka(alpha_RR)
     F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * smooth_sgn(v_x)
     beta = np.arctan(rear_weight_distribution * np.tan(delta))
     r_kin = np.sqrt(v_x * v_x + v_y * v_y) * np.sin(beta) / l_R
@@ -156,17 +159,21 @@ def fdyn6_residual(xdot, x, u, s_ref, kappa_ref):
     ])
 
 
-def fdyn6(x, u, s_ref, kappa_ref):
+def fdyn6(x, u, s_ref, kappa_ref, uncrossed=False):
     """Explicit xdot: the residual is affine in xdot, so one linear solve is exact."""
     x = np.asarray(x)
     dtype = np.result_type(x.dtype, np.asarray(u).dtype, np.float64)
-    r0 = fdyn6_residual(np.zeros(8, dtype=dtype), x, u, s_ref, kappa_ref)
+    r0 = fdyn6_residual(np.zeros(8, dtype=dtype), x, u, s_ref, kappa_ref, uncrossed)
     Jm = np.zeros((8, 8), dtype=dtype)
     for j in range(8):
         e = np.zeros(8, dtype=dtype)
         e[j] = 1.0
-        Jm[:, j] = fdyn6_residual(e, x, u, s_ref, kappa_ref) - r0
+        Jm[:, j] = fdyn6_residual(e, x, u, s_ref, kappa_ref, uncrossed) - r0
     return np.linalg.solve(Jm, -r0)
+
+
+def fdyn6u(x, u, s_ref, kappa_ref):
+    return fdyn6(x, u, s_ref, kappa_ref, uncrossed=True)
 
 
 def jac_complex_step(f, x, u, s_ref, kappa_ref, h=1e-30):

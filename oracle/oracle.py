@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libihm2_oracle.so")
 NX, NU, NZ, NY, NC, NG, NH = 8, 2, 10, 12, 14, 2, 2
-MODEL_FKIN6, MODEL_FDYN6 = 0, 1
+MODEL_FKIN6, MODEL_FDYN6, MODEL_FDYN6U = 0, 1, 2
 INTEG_RK4 = 0
 
 _dp = C.POINTER(C.c_double)

@@ -23,7 +23,7 @@ def track():
 def make_ocp(N=40, M=25, model="fkin6", n_max=2.0, **opts):
     from ihm2_amd import ocp as O
 
-    fn = O.fkin6_model if model == "fkin6" else O.fdyn6_model
+    fn = {"fkin6": O.fkin6_model, "fdyn6": O.fdyn6_model, "fdyn6u": O.fdyn6u_model}[model]
     mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, fn, 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, N, n_max, 31.0, 500.0, 0.5, 1e6, 1.0)
     ocp.cost.W, ocp.cost.W_e = O.default_weights()

@@ -198,20 +198,20 @@ def test_api_misuse_is_reported(track):
 
 
 # ---- dynamic (Pacejka) bicycle as the OCP model: BASELINE.json configs 3-4 without the soft path constraints ----
-@pytest.fixture(scope="module")
-def setup_dyn(track):
+@pytest.fixture(scope="module", params=["fdyn6", "fdyn6u"])
+def setup_dyn(track, request):
     from ihm2_amd.solver import BatchedOcpSolver
     from oracle import oracle as orc
 
     B = 40
-    ocp = make_ocp(model="fdyn6")
+    ocp = make_ocp(model=request.param)       # as written in the reference / with un-crossed slip angles
     solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
     P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
     x0 = sample_x0(track, B, seed=77)
     x0[:, 3] = np.linspace(4.0, 14.0, B)
     solver.set_x0(x0)
     solver.init_guess()          # kinematic Stanley rollout: a guess, the dynamic model sees defects
-    return dict(solver=solver, P=P, x0=x0, B=B)
+    return dict(solver=solver, P=P, x0=x0, B=B, model=request.param)
 
 
 def test_fdyn6_linearize_matches_oracle(setup_dyn):
@@ -240,8 +240,9 @@ def test_fdyn6_rti_step_matches_oracle(setup_dyn):
     out = P.rti_step(x, u, x0, yref, yref_e)
     assert np.mean(status == out["status"]) >= 0.95
     ok = (status == 0) & (out["status"] == 0)
-    # from a kinematic rollout the slow instances give the dynamic model infeasible QPs: both sides report 4
-    assert ok.sum() >= 0.5 * B
+    # from a kinematic rollout the slow instances give the dynamic model as written infeasible QPs (it is open-loop
+    # unstable, quirk Q3): both sides report 4.  The un-crossed variant solves (nearly) all of them.
+    assert ok.sum() >= (0.5 * B if setup_dyn["model"] == "fdyn6" else 0.9 * B)
     assert _rel(xg[ok], x[ok]) < 1e-6          # tolerance 1e-6 relative (north star: 1e-5)
     assert _rel(ug[ok], u[ok]) < 1e-6
     assert _rel(s.get_residuals(), out["res"]) < 1e-8
@@ -344,7 +345,7 @@ def _path_setup(track, model, soft, B, seed, width):
     solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, track_widths=w)
     P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref, track_widths=w))
     x0 = sample_x0(track, B, seed=seed)
-    if model == "fdyn6":
+    if model != "fkin6":
         x0[:, 3] = np.linspace(6.0, 14.0, B)
     solver.set_x0(x0)
     solver.init_guess()
@@ -355,7 +356,7 @@ def _path_setup(track, model, soft, B, seed, width):
     return solver, P, x0, yref, yref_e
 
 
-@pytest.mark.parametrize("model,soft,width", [("fkin6", False, 1.6), ("fkin6", True, 1.2), ("fdyn6", True, 1.2)])
+@pytest.mark.parametrize("model,soft,width", [("fkin6", False, 1.6), ("fkin6", True, 1.2), ("fdyn6", True, 1.2), ("fdyn6u", True, 1.2)])
 def test_track_rows_rti_steps_match_oracle(track, model, soft, width):
     B = 66
     s, P, x0, yref, yref_e = _path_setup(track, model, soft, B, 99, width)
@@ -378,7 +379,7 @@ def test_track_rows_rti_steps_match_oracle(track, model, soft, width):
         n_active += int((np.abs(lam[ok][:, :, 14 + 12:14 + 14]) > 1e-3).sum())
         # keep both sides on the same iterate (differences of 1e-7 would otherwise compound through the non-convex NLP)
         s.set_x(x); s.set_u(u); s.set_multipliers(pi, lam)
-        if model == "fkin6":
+        if model != "fdyn6":
             assert ok.sum() >= 0.9 * B
     assert n_active > 0                         # the rows really bind
     if soft:

@@ -10,7 +10,7 @@ from conftest import random_state
 from oracle import models_np as mnp
 from oracle import oracle as orc
 
-MODELS = [(orc.MODEL_FKIN6, mnp.fkin6), (orc.MODEL_FDYN6, mnp.fdyn6)]
+MODELS = [(orc.MODEL_FKIN6, mnp.fkin6), (orc.MODEL_FDYN6, mnp.fdyn6), (orc.MODEL_FDYN6U, mnp.fdyn6u)]
 
 
 def test_numpy_mirror_constants_match_golden():
@@ -78,6 +78,23 @@ def test_fdyn6_explicit_solves_reference_implicit_residual(track):
         res = mnp.fdyn6_residual(xdot, x, u, track.s_ref, track.kappa_ref)
         scale = np.array([1, 1, 1, mnp.m * 10, mnp.m * 10, mnp.I_z * 10, 1e3, 1e2])
         assert np.max(np.abs(res) / scale) < 1e-11
+
+
+def test_fdyn6_as_written_is_open_loop_unstable_and_uncrossed_is_not(track):
+    """Quirk Q3 (python/models.py:543-546: F_lat_FL uses alpha_RR, ...): the crossed slip angles turn the yaw/sideslip
+    feedback positive.  Straight driving at 10 m/s: eigenvalue +34 1/s as written, all <= 1 1/s un-crossed (the +0.84 is the
+    Frenet kinematics n' = v psi, shared with fkin6)."""
+    x = np.array([50.0, 0.0, 0.0, 10.0, 0.0, 0.0, 50.0, 0.0]); u = np.array([50.0, 0.0])
+    ev = {}
+    for mdl in (orc.MODEL_FKIN6, orc.MODEL_FDYN6, orc.MODEL_FDYN6U):
+        _, J = orc.jac(mdl, x, u, track.s_ref, track.kappa_ref)
+        ev[mdl] = np.linalg.eigvals(J[:, :8]).real.max()
+    assert ev[orc.MODEL_FDYN6] > 30.0
+    assert ev[orc.MODEL_FDYN6U] < 1.0 and abs(ev[orc.MODEL_FDYN6U] - ev[orc.MODEL_FKIN6]) < 1e-3
+    # and over one shooting interval (dt = 0.05, RK4 x 25): spectral radius 5.6 against 1.04
+    for mdl, lo, hi in ((orc.MODEL_FDYN6, 5.0, 6.5), (orc.MODEL_FDYN6U, 1.0, 1.1)):
+        _, A, _ = orc.rk4_sens(mdl, x, u, track.s_ref, track.kappa_ref, 0.05, 25)
+        assert lo < np.abs(np.linalg.eigvals(A)).max() < hi
 
 
 def test_kappa_interpolant(track):

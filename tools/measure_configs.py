@@ -20,7 +20,7 @@ from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 from ihm2_amd.track import track_table  # noqa: E402
 
 
-def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference"):
+def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None):
     plans = [track_table(t) for t in tracks]
     mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, O.fkin6_model if model == "fkin6" else O.fdyn6_model, 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
@@ -29,9 +29,19 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
     if terminal_bounds == "stage":      # see IHM2Controller(terminal_bounds=...): quirk Q1
         c = ocp.constraints
         c.idxbx_e, c.lbx_e, c.ubx_e = c.idxbx.copy(), c.lbx.copy(), c.ubx.copy()
+    widths = None
+    if track_rows is not None:          # nonlinear track-boundary rows, soft 100/100 as old/generate_acaods_interface.py:380-449
+        ocp.model.con_h_expr = "track"
+        c = ocp.constraints
+        c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+        if track_rows == "soft":
+            c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+            ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+            ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+        widths = np.array([[p.right_widths.min(), p.left_widths.min()] for p in plans])
     s_ref = np.stack([p.s_ref for p in plans]); k_ref = np.stack([p.kappa_ref for p in plans])
     tid = (np.arange(B) % len(plans)).astype(np.int32)
-    solver = BatchedOcpSolver(ocp, B, s_ref, k_ref, track_id=tid)
+    solver = BatchedOcpSolver(ocp, B, s_ref, k_ref, track_id=tid, track_widths=widths)
     x0 = np.zeros((B, 8))
     for t, p in enumerate(plans):
         sel = tid == t
@@ -53,7 +63,7 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
         step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
-    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
                qp_ms=tq / steps, status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
     solver.free()
@@ -78,7 +88,10 @@ def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference"):
 if __name__ == "__main__":
     all_tracks = ("fsds_competition_1", "fsds_competition_2", "fsds_competition_3", "fsds_default")
     for fn, kw in ((rti_throughput, dict(model="fkin6", B=1024)), (rti_throughput, dict(model="fkin6", B=8192)),
+                   (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage")),
+                   (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage", track_rows="soft")),
+                   (rti_throughput, dict(model="fdyn6", B=8192, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, tracks=all_tracks, terminal_bounds="stage")),
                    (closed_loop_config5, dict(B=4096, steps=200)),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage"))):
