@@ -51,6 +51,7 @@ SYMBOLS = {
     "ihm2mpc_set_stage": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p, c_double_p, C.c_int32]),
     "ihm2mpc_get_stage": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_char_p, c_double_p, C.c_int32]),
     "ihm2mpc_init_guess": (C.c_int, [_H, C.c_double]),
+    "ihm2mpc_reinit_failed": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_prepare_step": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_solve": (C.c_int, [_H, C.c_int32]),
     "ihm2mpc_linearize": (C.c_int, [_H]),

@@ -108,7 +108,9 @@ class IHM2Controller(Controller):
         soft_state_bounds: tuple | None = None,
         track_widths=None,
         track_rows_penalty: tuple | None = (100.0, 100.0),
+        recover_failed: bool = False,
     ) -> None:
+        self.recover_failed = recover_failed
         self.Nf, self.dt, self.s_target, self.B = Nf, dt, s_target, int(batch_size)
         self.config = Controller.Config(horizon_size=Nf, sampling_time=dt)
         self.model_bounds = ModelBounds(n_max=n_max, v_x_min=0.0, v_x_max=v_x_max, T_max=T_max, delta_max=delta_max,
@@ -192,6 +194,10 @@ class IHM2Controller(Controller):
         self.solver.prepare_step(self.s_target)            # yref ramp + warm-start shift, on device
         self.last_status = self.solver.solve()
         u0 = self.solver.get_u0()
+        if self.recover_failed:
+            # not in the reference (its loop stops at the first bad status, python/main.py:326-328): give the failed instances a
+            # fresh rollout as the next warm start instead of the iterate that made their QP infeasible
+            self.solver.reinit_failed()
         bad = ~np.isin(self.last_status, (0, 2))
         if single:
             return None if bad[0] else u0[0]

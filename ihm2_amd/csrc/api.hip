@@ -456,7 +456,16 @@ int ihm2mpc_init_guess(ihm2mpc_handle *h, double v_ref_scale)
 {
     CHECK_H(h);
     if (ready(h)) return -1;
-    ihm2_launch_init_guess(h, v_ref_scale);
+    ihm2_launch_init_guess(h, v_ref_scale, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ihm2mpc_reinit_failed(ihm2mpc_handle *h, double v_ref_scale)
+{
+    CHECK_H(h);
+    if (ready(h)) return -1;
+    ihm2_launch_init_guess(h, v_ref_scale, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -78,7 +78,7 @@ struct ihm2mpc_handle {
 
 // --- launchers (each defined in one .hip file) ---
 void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target);
-void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale);
+void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn);

@@ -44,15 +44,26 @@ __global__ __launch_bounds__(64) void k_prepare(int B, int N, double s_target, c
     }
 }
 
+// MODEL: the model the rollout integrates -- the OCP's own model where that is usable as a simulator (fkin6, fdyn6u), the
+// kinematic one for fdyn6 as written (open-loop unstable over the horizon).
+// only_failed != nullptr: re-initialise only the instances whose last status is non-zero, and clear their multipliers.
+template <int MODEL>
 __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double dt, double v_ref_scale, int nknots,
                                                    const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                                    const int32_t *__restrict__ track_id, const double *__restrict__ x0,
                                                    const double *__restrict__ lbu, const double *__restrict__ ubu,
                                                    const double *__restrict__ lg, const double *__restrict__ ug,
-                                                   double *__restrict__ xs, double *__restrict__ us)
+                                                   double *__restrict__ xs, double *__restrict__ us,
+                                                   const int32_t *__restrict__ only_failed, double *__restrict__ pi,
+                                                   double *__restrict__ lam)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
+    if (only_failed) {
+        if (only_failed[b] == 0) return;
+        for (int e = 0; e < (N + 1) * 8; e++) pi[(size_t)b * (N + 1) * 8 + e] = 0.0;
+        for (int e = 0; e < (N + 1) * NLAM; e++) lam[(size_t)b * (N + 1) * NLAM + e] = 0.0;
+    }
     double x[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) x[i] = x0[(size_t)b * 8 + i];
@@ -88,7 +99,8 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
                 double X[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
-                fkin6_eval<false>(X, u_T, u_d, trk, K, J);
+                if (MODEL == IHM2MPC_MODEL_FDYN6U) fdyn6_eval<false, true>(X, u_T, u_d, trk, K, J);
+                else fkin6_eval<false>(X, u_T, u_d, trk, K, J);
 #pragma unroll
                 for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
             }
@@ -108,9 +120,14 @@ void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target)
                        h->yref_e);
 }
 
-void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale)
+void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed)
 {
-    hipLaunchKernelGGL(k_init_guess, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
-                       v_ref_scale, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x0, h->lbu, h->ubu, h->lg, h->ug,
-                       h->x, h->u);
+    const int32_t *mask = only_failed ? h->status : nullptr;
+#define LAUNCH_IG(MD)                                                                                                          \
+    hipLaunchKernelGGL(k_init_guess<MD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,      \
+                       v_ref_scale, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x0, h->lbu, h->ubu, h->lg, h->ug,    \
+                       h->x, h->u, mask, h->pi, h->lam)
+    if (h->cfg.model == IHM2MPC_MODEL_FDYN6U) LAUNCH_IG(IHM2MPC_MODEL_FDYN6U);
+    else LAUNCH_IG(IHM2MPC_MODEL_FKIN6);
+#undef LAUNCH_IG
 }

@@ -173,6 +173,10 @@ class BatchedOcpSolver:
     def init_guess(self, v_ref_scale: float = 1.0):
         _lib.check(self.lib.ihm2mpc_init_guess(self._h, float(v_ref_scale)))
 
+    def reinit_failed(self, v_ref_scale: float = 1.0):
+        """Re-roll the warm start of the instances whose last solve failed (status != 0) from their current ``x0``."""
+        _lib.check(self.lib.ihm2mpc_reinit_failed(self._h, float(v_ref_scale)))
+
     def prepare_step(self, s_target: float):
         """Reference ramp + warm-start shift of ``compute_control`` (``python/main.py:303-322``) on device."""
         _lib.check(self.lib.ihm2mpc_prepare_step(self._h, float(s_target)))

@@ -129,6 +129,10 @@ int ihm2mpc_get_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const 
 /* ---- the hot path ---- */
 /* initial guess: roll the model out from x0 under a Stanley-type feedback (python/main.py:99-163) */
 int ihm2mpc_init_guess(ihm2mpc_handle *h, double v_ref_scale);
+/* the same rollout for the instances whose last solve failed (status != 0) only, multipliers cleared: a failed instance keeps
+ * its iterate, which can keep it infeasible for ever; the reference stops its single loop instead
+ * (python/main.py:326-328).  Call between solve() and the next prepare_step(). */
+int ihm2mpc_reinit_failed(ihm2mpc_handle *h, double v_ref_scale);
 /* reference ramp yref_j = [s0 + s_target*j/N, 0..], yref_e = [s0 + s_target, 0..] from the current
  * x0, and warm-start shift of (x,u) -- python/main.py:303-322 -- entirely on device */
 int ihm2mpc_prepare_step(ihm2mpc_handle *h, double s_target);

@@ -20,9 +20,9 @@ from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 from ihm2_amd.track import track_table  # noqa: E402
 
 
-def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None):
+def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False):
     plans = [track_table(t) for t in tracks]
-    mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, O.fkin6_model if model == "fkin6" else O.fdyn6_model, 8, 2, 3000)
+    mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, {"fkin6": O.fkin6_model, "fdyn6": O.fdyn6_model, "fdyn6u": O.fdyn6u_model}[model], 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
     ocp.cost.W, ocp.cost.W_e = O.default_weights()
     ocp.solver_options.tf = 2.0
@@ -47,40 +47,43 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
         sel = tid == t
         x0[sel] = bench.sample_x0(p, int(sel.sum()), seed=20240607 + t)
     solver.set_x0(x0); solver.init_guess()
-    if model == "fdyn6":          # a few SQP iterations on the frozen problem: the kinematic rollout is not a dynamic trajectory
+    if model != "fkin6":          # a few SQP iterations on the frozen problem: the kinematic rollout is not a dynamic trajectory
         yref = np.zeros((B, 40, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(40)[None] / 40
         yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
         solver.set_yref(yref); solver.set_yref_e(yref_e); solver.solve(3)
-    plant = 0 if model == "fkin6" else 1
+    plant = {"fkin6": 0, "fdyn6": 1, "fdyn6u": 2}[model]
 
     def step():
-        solver.sim_advance(model=plant, M_sim=25); solver.prepare_step(40.0); solver.solve_async(); return solver.get_u0()
+        solver.sim_advance(model=plant, M_sim=25); solver.prepare_step(40.0); solver.solve_async(); u0 = solver.get_u0()
+        if recover:
+            solver.reinit_failed()
+        return u0
 
     for _ in range(warmup):
         step()
-    solver.synchronize(); t0 = time.perf_counter(); tl = tq = 0.0
+    solver.synchronize(); t0 = time.perf_counter(); tl = tq = 0.0; n_ok = 0
     for _ in range(steps):
-        step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]
+        step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]; n_ok += int((solver.get_status() == 0).sum())
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
-    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
-               qp_ms=tq / steps, status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
+    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+               qp_ms=tq / steps, ok_fraction=n_ok / (B * steps), status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
     solver.free()
     return out
 
 
-def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference"):
+def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="KIN6_DYN6", soft_state_bounds=None):
     plan = track_table("fsds_competition_1")
-    ctrl = IHM2Controller(plan.s_ref, plan.kappa_ref, batch_size=B, terminal_bounds=terminal_bounds)
-    sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=100), SimModelVariant.KIN6_DYN6)
+    ctrl = IHM2Controller(plan.s_ref, plan.kappa_ref, batch_size=B, terminal_bounds=terminal_bounds, soft_state_bounds=soft_state_bounds)
+    sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=100), SimModelVariant[plant])
     x0 = bench.sample_x0(plan, B, seed=5)
     ctrl.warm_start(x0)
     t0 = time.perf_counter()
     res = run_closed_loop(ctrl, sim, x0, steps, lap_length=plan.lap_length)
     el = time.perf_counter() - t0
     st = res.stats()
-    return dict(config=5, terminal_bounds=terminal_bounds, B=B, steps=int(res.u.shape[0]), wall_s=el, control_steps_per_s=B * res.u.shape[0] / el, alive=int(res.alive.sum()),
+    return dict(config=5, terminal_bounds=terminal_bounds, plant=plant, soft_state_bounds=soft_state_bounds, B=B, steps=int(res.u.shape[0]), wall_s=el, control_steps_per_s=B * res.u.shape[0] / el, alive=int(res.alive.sum()),
                 finished=int(res.finished.sum()), failed=st["failed"], mean_speed=st["mean_speed"],
                 progress_m_median=float(np.median(res.x[-1, :, 0] - res.x[0, :, 0])))
 
@@ -94,5 +97,11 @@ if __name__ == "__main__":
                    (rti_throughput, dict(model="fdyn6", B=8192, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, tracks=all_tracks, terminal_bounds="stage")),
                    (closed_loop_config5, dict(B=4096, steps=200)),
-                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage"))):
+                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage")),
+                   # the same configurations with the un-crossed dynamic model (named deviation from quirk Q3)
+                   (rti_throughput, dict(model="fdyn6u", B=8192, track_rows="soft")),
+                   (rti_throughput, dict(model="fdyn6u", B=8192, terminal_bounds="stage", track_rows="soft", recover=True)),
+                   (rti_throughput, dict(model="fdyn6u", B=8192, tracks=all_tracks, terminal_bounds="stage", track_rows="soft", recover=True)),
+                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U")),
+                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0)))):
         print(json.dumps(fn(**kw)), flush=True)
