@@ -20,7 +20,7 @@ from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 from ihm2_amd.track import track_table  # noqa: E402
 
 
-def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False):
+def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False, host_state=False):
     plans = [track_table(t) for t in tracks]
     mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, {"fkin6": O.fkin6_model, "fdyn6": O.fdyn6_model, "fdyn6u": O.fdyn6u_model}[model], 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
@@ -54,7 +54,10 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
     plant = {"fkin6": 0, "fdyn6": 1, "fdyn6u": 2}[model]
 
     def step():
-        solver.sim_advance(model=plant, M_sim=25); solver.prepare_step(40.0); solver.solve_async(); u0 = solver.get_u0()
+        solver.sim_advance(model=plant, M_sim=25)
+        if host_state:      # the state crosses the boundary as host buffers every step: D2H (B,8) + H2D (B,8) on top of the u0 readback
+            solver.set_x0(solver.get_x0())
+        solver.prepare_step(40.0); solver.solve_async(); u0 = solver.get_u0()
         if recover:
             solver.reinit_failed()
         return u0
@@ -66,7 +69,7 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
         step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]; n_ok += int((solver.get_status() == 0).sum())
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
-    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
                qp_ms=tq / steps, ok_fraction=n_ok / (B * steps), status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
     solver.free()
@@ -90,7 +93,8 @@ def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="K
 
 if __name__ == "__main__":
     all_tracks = ("fsds_competition_1", "fsds_competition_2", "fsds_competition_3", "fsds_default")
-    for fn, kw in ((rti_throughput, dict(model="fkin6", B=1024)), (rti_throughput, dict(model="fkin6", B=8192)),
+    for fn, kw in ((rti_throughput, dict(model="fkin6", B=1024)), (rti_throughput, dict(model="fkin6", B=1024, host_state=True)),
+                   (rti_throughput, dict(model="fkin6", B=8192)),
                    (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage", track_rows="soft")),
