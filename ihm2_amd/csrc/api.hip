@@ -150,7 +150,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     for (size_t i = 0; i < NS * NLAM; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
     DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(u0, B * 2);
-    DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, B * N * 64); DA(q_Mt, B * N * 64); DA(scratch, B * 24);
+    DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, B * N * 64); DA(scratch, B * 24);
 #undef DA
     *out = h;
     return 0;
@@ -163,7 +163,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
-                    h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->q_Mt, h->scratch};
+                    h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);

@@ -72,7 +72,7 @@ struct ihm2mpc_handle {
     // ---- QP workspace in HBM/L2 (everything else of the QP lives in LDS / registers) ----
     double *q_g;    // (B,NS,10) QP gradient
     double *q_P;    // (B,NS,64) Riccati matrices of the current factorisation
-    double *q_M, *q_Mt;   // (B,N,64) closed-loop matrices A - B K, row-major and transposed
+    double *q_M;    // (B,N,64) closed-loop matrices A - B K (row-major; the vector recursion reads them transposed)
     double *scratch;   // (B, 3*8) plant scratch
 };
 

@@ -41,7 +41,7 @@ struct QpArgs {
     double *pi, *lam, *res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g, *P, *M, *Mt, *slk;
+    double *g, *P, *M, *slk;
     // track rows
     const int32_t *track_id;
     const double *widths;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
     double *gb = a.g + (size_t)b * NS * 10;
     double *Pg = a.P + (size_t)b * NS * 64;
-    double *Mg = a.M + (size_t)b * N * 64, *Mtg = a.Mt + (size_t)b * N * 64;
+    double *Mg = a.M + (size_t)b * N * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 28;
     double *slkb = a.slk + (size_t)b * NS * 28;
@@ -588,32 +588,29 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                         Gs[gj * 10 + gi] = acc;
                     }
                     WSYNC();
-                    // P_k = Gxx - Gux' Guu^-1 Gux ; K_k = Guu^-1 Gux
+                    // P_k = Gxx - Gux' Guu^-1 Gux ; K_k = Guu^-1 Gux ; closed-loop matrix M_k = A - B K_k (streamed back by the
+                    // vector recursion, which reads it with the transposed lane map -- the same 512 bytes -- and by the
+                    // forward recursion).  One phase: every lane forms the two entries of K it needs from the G column it
+                    // has already read.
                     {
                         const double g00 = Gs[88], g01 = Gs[89], g11 = Gs[99];
-                        const double idet = 1.0 / (g00 * g11 - g01 * g01);
-                        const double Gi0 = g11 * idet, Gi1 = -g01 * idet, Gi2 = g00 * idet;
                         const int i0 = lane >> 3, j0 = lane & 7;
                         const int i = min(i0, j0), j = max(i0, j0);      // evaluate the symmetric pair identically
                         const double ai = Gs[i * 10 + 8], bi = Gs[i * 10 + 9], cj = Gs[j * 10 + 8], dj = Gs[j * 10 + 9];
-                        const double v = Gs[i * 10 + j] - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
+                        const double gij = Gs[i * 10 + j];
+                        const double a_own = AB[lane], b0 = AB[64 + i0 * 2], b1 = AB[64 + i0 * 2 + 1];
+                        const double idet = 1.0 / (g00 * g11 - g01 * g01);
+                        const double Gi0 = g11 * idet, Gi1 = -g01 * idet, Gi2 = g00 * idet;
+                        const double v = gij - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
                         Pn[lane] = v;
                         Pg[(size_t)k * 64 + lane] = v;
-                        if (lane < 16) {      // K[a][jj], a = lane >> 3
-                            const int jj = lane & 7;
-                            const double gx0 = Gs[jj * 10 + 8], gx1 = Gs[jj * 10 + 9];
-                            Kl[k * 16 + lane] = (lane < 8) ? (Gi0 * gx0 + Gi1 * gx1) : (Gi1 * gx0 + Gi2 * gx1);
-                        }
+                        const double gx0 = (j0 == i) ? ai : cj, gx1 = (j0 == i) ? bi : dj;      // G[j0][8], G[j0][9]
+                        const double K0 = Gi0 * gx0 + Gi1 * gx1, K1 = Gi1 * gx0 + Gi2 * gx1;     // K[0][j0], K[1][j0]
+                        if (lane < 16) Kl[k * 16 + lane] = (lane < 8) ? K0 : K1;
                         if (lane == 0) { Ginv[k * 4 + 0] = Gi0; Ginv[k * 4 + 1] = Gi1; Ginv[k * 4 + 2] = Gi2; }
+                        Mg[(size_t)k * 64 + lane] = a_own - b0 * K0 - b1 * K1;
                     }
                     WSYNC();
-                    // closed-loop matrix M_k = A - B K in both lane layouts (row-major for the forward
-                    // recursion, transposed for the vector recursion), streamed back by those sweeps
-                    {
-                        const int hi = lane >> 3, lo = lane & 7;
-                        Mg[(size_t)k * 64 + lane] = AB[hi * 8 + lo] - AB[64 + hi * 2] * Kl[k * 16 + lo] - AB[64 + hi * 2 + 1] * Kl[k * 16 + 8 + lo];
-                        Mtg[(size_t)k * 64 + lane] = AB[lo * 8 + hi] - AB[64 + lo * 2] * Kl[k * 16 + hi] - AB[64 + lo * 2 + 1] * Kl[k * 16 + 8 + hi];
-                    }
                 });
             }
 
@@ -631,7 +628,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             // ... then one multiply + an 8-lane DPP sum per stage: lane (j, l) holds M_k[l][j]
             {
                 const int j = lane >> 3, l = lane & 7;
-                stream_rows<-1, 8>(Mtg, N, lane, [&](int k, double m) {
+                stream_rows<-1, 8>(Mg, N, (l << 3) | j, [&](int k, double m) {
                     const double t = sum8(m * (Prb[k * 8 + l] + pv[(k + 1) * 8 + l]));
                     if (l == 0) pv[k * 8 + j] += t;
                     WSYNC();
@@ -826,7 +823,7 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M; a.Mt = h->q_Mt;
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M;
     const int N = h->N, NS = h->NS;
     const int nck = h->path_on ? 14 : 12;
     const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
