@@ -183,6 +183,54 @@ __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2,
     }
 }
 
+// Forward sweep over PAIRS of stages whose work does not depend on the previous stage: two records are staged per step
+// (4 LDS slots) and body(k, rec_k, rec_k1, has_k1) treats both, so every LDS wait and the closing fence are shared by two
+// stages.  Ring depth D pairs.  body must end with WSYNC().
+template <int D, typename F>
+__device__ __forceinline__ void stream_pairs(const double *linb, double *stage4, int N, int lane, F &&body)
+{
+    const int l2 = (lane < 24) ? 64 + lane : lane;
+    double ra[D][2], rb2[D][2];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int kk = min(2 * d + q, N - 1);
+            ra[d][q] = linb[(size_t)kk * LIN_REC + lane];
+            rb2[d][q] = linb[(size_t)kk * LIN_REC + l2];
+        }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        stage4[q * LIN_REC + lane] = ra[0][q];
+        if (lane < 24) stage4[q * LIN_REC + 64 + lane] = rb2[0][q];
+    }
+    WSYNC();
+    const int NP = (N + 1) / 2;
+    for (int p0 = 0; p0 < NP; p0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int p = p0 + d;
+            double *cur = stage4 + (p & 1) * 2 * LIN_REC, *nxt = stage4 + ((p + 1) & 1) * 2 * LIN_REC;
+            double na[2], nb[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                na[q] = ra[(d + 1) % D][q]; nb[q] = rb2[(d + 1) % D][q];
+                const int kk = min(2 * (p + D) + q, N - 1);          // unconditional, clamped (see stream_sweep)
+                ra[d][q] = linb[(size_t)kk * LIN_REC + lane];
+                rb2[d][q] = linb[(size_t)kk * LIN_REC + l2];
+            }
+            if (p < NP) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    nxt[q * LIN_REC + lane] = na[q];
+                    if (lane < 24) nxt[q * LIN_REC + 64 + lane] = nb[q];
+                }
+                body(2 * p, cur, cur + LIN_REC, 2 * p + 1 < N);
+            }
+        }
+    }
+}
+
 template <int NSLOT, int NSOFT, int PATH>
 __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 {
@@ -436,22 +484,38 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
         // between stages).  Branch-free: every lane forms one product of each 8x8 part and the 8-term sums
         // are DPP reductions -- lane (o, l): A[l][o] pi_{k+1}[l] (column o of A) and A[o][l] z_k[l] (row o).
+        // Stages are independent here: two per step (the 4 staging slots overlay stage2 | Pn | Ws | Gs, which only the
+        // factor sweep uses), all LDS reads of both before any write.
         {
             const int o = lane >> 3, l = lane & 7;
-            stream_sweep<+1, 4>(linb, stage2, N, lane, [&](int k, const double *AB) {
-                const double tp = sum8(AB[l * 8 + o] * pi[(k + 1) * 8 + l]);
-                const double tz = sum8(AB[o * 8 + l] * z[k * 10 + l]);
-                // the two input columns / rows: lanes (o, 0) add B-terms to rb, lanes (0,1),(1,1) do B' pi
-                double bp = 0.0;
-                if (l == 1 && o < 2) {
+            stream_pairs<2>(linb, stage2, N, lane, [&](int k, const double *AB0, const double *AB1, bool two) {
+                const double *ABq[2] = {AB0, AB1};
+                double tp[2], tz[2], bp[2], rbv[2];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) bp = fma(AB[64 + q * 2 + o], pi[(k + 1) * 8 + q], bp);
+                for (int q = 0; q < 2; q++) {
+                    const double *AB = ABq[q];
+                    const int kq = k + q;
+                    const int kn = min(kq + 1, N);              // stays inside pi / z for the clamped duplicate of an odd tail
+                    const double pl = pi[kn * 8 + l];
+                    tp[q] = sum8(AB[l * 8 + o] * pl);
+                    // row o of [A B] times z_k: lanes l < 2 carry the two input columns as a second product
+                    double prod = AB[o * 8 + l] * z[kq * 10 + l];
+                    if (l < 2) prod = fma(AB[64 + o * 2 + l], z[kq * 10 + 8 + l], prod);
+                    tz[q] = sum8(prod);
+                    // B' pi_{k+1}: lanes (o < 2, l) hold B[l][o] pi[l]
+                    bp[q] = sum8((o < 2) ? AB[64 + l * 2 + o] * pl : 0.0);
+                    rbv[q] = 0.0;
+                    if (l == 0) rbv[q] = tz[q] + AB[80 + o] - z[kn * 10 + o];
                 }
-                if (l == 0) {
-                    gt[k * 10 + o] += tp;
-                    rb[k * 8 + o] = tz + AB[80 + o] - z[(k + 1) * 10 + o] + AB[64 + o * 2] * z[k * 10 + 8] + AB[64 + o * 2 + 1] * z[k * 10 + 9];
-                } else if (l == 1 && o < 2) {
-                    gt[k * 10 + 8 + o] += bp;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    if (q == 1 && !two) continue;
+                    const int kq = k + q;
+                    if (l == 0) {
+                        gt[kq * 10 + o] += tp[q];
+                        rb[kq * 8 + o] = rbv[q];
+                        if (o < 2) gt[kq * 10 + 8 + o] += bp[q];
+                    }
                 }
                 WSYNC();
             });
