@@ -95,8 +95,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // every lane of these permutations has an in-range source, so the "old" operand is never used: passing the value itself
+    // saves the two zero-initialising moves a constant would cost per step
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double sum8(double v)
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         // factor sweep uses), all LDS reads of both before any write.
         {
             const int o = lane >> 3, l = lane & 7;
+            const double m_l2 = (l < 2) ? 1.0 : 0.0, m_o2 = (o < 2) ? 1.0 : 0.0;
             stream_pairs<2>(linb, stage2, N, lane, [&](int k, const double *AB0, const double *AB1, bool two) {
                 const double *ABq[2] = {AB0, AB1};
                 double tp[2], tz[2], bp[2], rbv[2];
@@ -498,20 +501,18 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     const int kn = min(kq + 1, N);              // stays inside pi / z for the clamped duplicate of an odd tail
                     const double pl = pi[kn * 8 + l];
                     tp[q] = sum8(AB[l * 8 + o] * pl);
-                    // row o of [A B] times z_k: lanes l < 2 carry the two input columns as a second product
-                    double prod = AB[o * 8 + l] * z[kq * 10 + l];
-                    if (l < 2) prod = fma(AB[64 + o * 2 + l], z[kq * 10 + 8 + l], prod);
-                    tz[q] = sum8(prod);
+                    // row o of [A B] times z_k: lanes l < 2 carry the two input columns as a second product (all lanes
+                    // read, a 0/1 factor selects: cheaper than an exec-mask branch on a single wave)
+                    tz[q] = sum8(fma(AB[64 + o * 2 + (l & 1)] * m_l2, z[kq * 10 + 8 + (l & 1)], AB[o * 8 + l] * z[kq * 10 + l]));
                     // B' pi_{k+1}: lanes (o < 2, l) hold B[l][o] pi[l]
-                    bp[q] = sum8((o < 2) ? AB[64 + l * 2 + o] * pl : 0.0);
-                    rbv[q] = 0.0;
-                    if (l == 0) rbv[q] = tz[q] + AB[80 + o] - z[kn * 10 + o];
+                    bp[q] = sum8(AB[64 + l * 2 + (o & 1)] * pl * m_o2);
+                    rbv[q] = tz[q] + AB[80 + o] - z[kn * 10 + o];
                 }
+                if (l == 0) {
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    if (q == 1 && !two) continue;
-                    const int kq = k + q;
-                    if (l == 0) {
+                    for (int q = 0; q < 2; q++) {
+                        if (q == 1 && !two) continue;
+                        const int kq = k + q;
                         gt[kq * 10 + o] += tp[q];
                         rb[kq * 8 + o] = rbv[q];
                         if (o < 2) gt[kq * 10 + 8 + o] += bp[q];
