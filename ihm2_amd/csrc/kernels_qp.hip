@@ -647,8 +647,12 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                             const double g12 = gam[k * NCK + 12], g13 = gam[k * NCK + 13], a0 = hc[k * 2], a1 = hc[k * 2 + 1];
                             acc += (hsel == 1) ? g12 + g13 : (hsel == 2) ? g12 * a0 - g13 * a1 : g12 * a0 * a0 + g13 * a1 * a1;
                         }
+                        // all 16 operands first: issued back to back they cost one LDS latency, not eight
+                        double av[8], wv[8];
 #pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(AB[ci + l * si], Ws[l * 10 + gj], acc);
+                        for (int l = 0; l < 8; l++) { av[l] = AB[ci + l * si]; wv[l] = Ws[l * 10 + gj]; }
+#pragma unroll
+                        for (int l = 0; l < 8; l++) acc = fma(av[l], wv[l], acc);
                         Gs[gi * 10 + gj] = acc;
                         Gs[gj * 10 + gi] = acc;
                     }
