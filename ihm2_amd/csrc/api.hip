@@ -250,6 +250,10 @@ int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e)
             for (int j = 0; j < i; j++)
                 if (fabs(Hs[((size_t)k * 10 + i) * 10 + j] - Hs[((size_t)k * 10 + j) * 10 + i]) > 1e-12 * (1 + fabs(Hs[((size_t)k * 10 + i) * 10 + j])))
                     return fail("weight matrix of stage %d is not symmetric", k);
+    h->uniform_H = true;
+    for (int k = 1; k < N && h->uniform_H; k++)
+        for (int i = 0; i < 100; i++)
+            if (Hs[(size_t)k * 100 + i] != Hs[i]) { h->uniform_H = false; break; }
     if (upload_shared(h, Hs.data(), h->Hs, Hs.size()) || upload_shared(h, Gy.data(), h->Gy, Gy.size())) return -1;
     h->weights_set = true;
     return 0;
@@ -334,6 +338,10 @@ int ihm2mpc_set_bounds(ihm2mpc_handle *h, const double *lbx, const double *ubx, 
             for (int j = 0; j < NX; j++) CD[((size_t)k * 2 + r) * 10 + j] = C[((size_t)k * 2 + r) * NX + j];
             for (int j = 0; j < NU; j++) CD[((size_t)k * 2 + r) * 10 + 8 + j] = D[((size_t)k * 2 + r) * NU + j];
         }
+    h->uniform_CD = true;
+    for (int k = 1; k < N && h->uniform_CD; k++)
+        for (int i = 0; i < 20; i++)
+            if (CD[(size_t)k * 20 + i] != CD[i]) { h->uniform_CD = false; break; }
     for (int k = 0; k < NS; k++)
         for (int c = 0; c < 12; c++) {       // rows 12, 13 belong to set_path_constraints
             double lb = -INFINITY, ub = INFINITY;

@@ -30,6 +30,7 @@ struct ihm2mpc_handle {
     hipStream_t stream;
     hipEvent_t ev[4];
     bool tracks_set, weights_set, bounds_set;
+    bool uniform_H, uniform_CD;    // stage Hessians / general rows identical for all k < N (QP kernel keeps them in LDS)
 
     // ---- shared problem data (device) ----
     double *s_ref, *kappa_ref;     // (ntracks, nknots)

@@ -233,7 +233,7 @@ __device__ __forceinline__ void stream_pairs(const double *linb, double *stage4,
     }
 }
 
-template <int NSLOT, int NSOFT, int PATH>
+template <int NSLOT, int NSOFT, int PATH, int UNI>
 __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 {
     extern __shared__ double sm[];
@@ -243,6 +243,10 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     // constraint rows per stage held in LDS: 8 x boxes, 2 u boxes, 2 general rows (+ 2 track rows); the multiplier arrays in
     // HBM always have the full NLAM = 28 columns (14 lower sides, then 14 upper sides)
     constexpr int NCK = PATH ? 14 : 12;
+    // UNI: the stage Hessians H_0..H_{N-1} and the general rows [C D]_k do not depend on k (the reference's OCP: one W, one C, D
+    // for all stages, python/mpc.py:49-99).  They are then kept in LDS (H only where the budget of 40 KB per instance allows)
+    // instead of being fetched through L2 with lane-dependent addresses in every phase.
+    constexpr bool HL = UNI && !PATH, CL = UNI;
 
     // ---- LDS carve-up (doubles) ----
     double *z = sm;                  // NS*10  QP iterate
@@ -262,6 +266,10 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     double *Ws = Pn + 64;            // 80     [l][10]
     double *Gs = Ws + 80;            // 100
     double *hc = Gs + 100;           // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
+    double *Hl = hc + (PATH ? NS * 2 : 0);   // 200  stage and terminal Hessian (HL only)
+    double *CDl = Hl + (HL ? 200 : 0);       // 20   general rows (CL only)
+#define HS(k, i, l) (HL ? Hl[(((k) == N) ? 100 : 0) + (i) * 10 + (l)] : a.Hs[((k) * 10 + (i)) * 10 + (l)])
+#define CDV(k, r, j) (CL ? CDl[(r) * 10 + (j)] : a.CD[((k) * 2 + (r)) * 10 + (j)])
 
     const double *xb = a.x + (size_t)b * NS * 8;
     const double *ub = a.u + (size_t)b * N * 2;
@@ -275,6 +283,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
+    if (HL) for (int e = lane; e < 200; e += 64) Hl[e] = a.Hs[(e < 100) ? e : N * 100 + (e - 100)];
+    if (CL && lane < 20) CDl[lane] = a.CD[lane];
+    if (UNI) WSYNC();
     double sg = 1.0, sb = 1.0, r_stat = 0.0, r_eq = 0.0;
     double w_R = 0.0, w_L = 0.0;
     if (PATH) {
@@ -295,10 +306,10 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         const int k = e / 10, j = e % 10;
         double acc = 0.0;
 #pragma unroll
-        for (int l = 0; l < 8; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], xb[k * 8 + l], acc);
+        for (int l = 0; l < 8; l++) acc = fma(HS(k, j, l), xb[k * 8 + l], acc);
         if (k < N) {
-            acc = fma(a.Hs[(k * 10 + j) * 10 + 8], ub[k * 2 + 0], acc);
-            acc = fma(a.Hs[(k * 10 + j) * 10 + 9], ub[k * 2 + 1], acc);
+            acc = fma(HS(k, j, 8), ub[k * 2 + 0], acc);
+            acc = fma(HS(k, j, 9), ub[k * 2 + 1], acc);
             const double *yr = a.yref + ((size_t)b * N + k) * 12;
 #pragma unroll
             for (int l = 0; l < 12; l++) acc = fma(-a.Gy[(k * 10 + j) * 12 + l], yr[l], acc);
@@ -320,8 +331,8 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (j < 8) st -= pib[k * 8 + j];
         st -= lamb[k * 28 + j] - lamb[k * 28 + 14 + j];
         if (k < N) {
-            st = fma(-a.CD[(k * 2 + 0) * 10 + j], lamb[k * 28 + 10] - lamb[k * 28 + 24], st);
-            st = fma(-a.CD[(k * 2 + 1) * 10 + j], lamb[k * 28 + 11] - lamb[k * 28 + 25], st);
+            st = fma(-CDV(k, 0, j), lamb[k * 28 + 10] - lamb[k * 28 + 24], st);
+            st = fma(-CDV(k, 1, j), lamb[k * 28 + 11] - lamb[k * 28 + 25], st);
         }
         if (PATH && (j == 1 || j == 2)) {
             const double l12 = lamb[k * 28 + 12] - lamb[k * 28 + 26], l13 = lamb[k * 28 + 13] - lamb[k * 28 + 27];
@@ -374,9 +385,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             } else {
                 cz = 0.0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) cz = fma(a.CD[(k * 2 + c - 10) * 10 + j], xb[k * 8 + j], cz);
-                cz = fma(a.CD[(k * 2 + c - 10) * 10 + 8], ub[k * 2 + 0], cz);
-                cz = fma(a.CD[(k * 2 + c - 10) * 10 + 9], ub[k * 2 + 1], cz);
+                for (int j = 0; j < 8; j++) cz = fma(CDV(k, c - 10, j), xb[k * 8 + j], cz);
+                cz = fma(CDV(k, c - 10, 8), ub[k * 2 + 0], cz);
+                cz = fma(CDV(k, c - 10, 9), ub[k * 2 + 1], cz);
             }
             const double lb = a.slot_lb[s], ubd = a.slot_ub[s];
             bool soft = false;
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (PATH && c >= 12) return (c == 12) ? v[k * 10 + 1] + hc[k * 2] * v[k * 10 + 2] : -v[k * 10 + 1] + hc[k * 2 + 1] * v[k * 10 + 2];
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 10; j++) acc = fma(a.CD[(k * 2 + c - 10) * 10 + j], v[k * 10 + j], acc);
+        for (int j = 0; j < 10; j++) acc = fma(CDV(k, c - 10, j), v[k * 10 + j], acc);
         return acc;
     };
 
@@ -469,10 +480,10 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             const int k = e / 10, j = e % 10;
             double acc = gb[e];
 #pragma unroll
-            for (int l = 0; l < 10; l++) acc = fma(a.Hs[(k * 10 + j) * 10 + l], z[k * 10 + l], acc);
+            for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
             if (k < N) {
-                acc = fma(-a.CD[(k * 2 + 0) * 10 + j], cf[k * NCK + 10], acc);
-                acc = fma(-a.CD[(k * 2 + 1) * 10 + j], cf[k * NCK + 11], acc);
+                acc = fma(-CDV(k, 0, j), cf[k * NCK + 10], acc);
+                acc = fma(-CDV(k, 1, j), cf[k * NCK + 11], acc);
             }
             if (j < 8) acc -= pi[k * 8 + j];
             acc -= cf[k * NCK + j];
@@ -578,8 +589,8 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 const int k = e / 10, j = e % 10;
                 double acc = gt[e] + cf[k * NCK + j];
                 if (k < N) {
-                    acc = fma(a.CD[(k * 2 + 0) * 10 + j], cf[k * NCK + 10], acc);
-                    acc = fma(a.CD[(k * 2 + 1) * 10 + j], cf[k * NCK + 11], acc);
+                    acc = fma(CDV(k, 0, j), cf[k * NCK + 10], acc);
+                    acc = fma(CDV(k, 1, j), cf[k * NCK + 11], acc);
                 }
                 if (PATH && (j == 1 || j == 2)) {
                     const double c12 = cf[k * NCK + 12], c13 = cf[k * NCK + 13];
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             if (pass == 0) {
                 {   // terminal stage
                     const int i = lane >> 3, j = lane & 7;
-                    double v = a.Hs[(N * 10 + i) * 10 + j];
+                    double v = HS(N, i, j);
                     if (i == j) v += gam[N * NCK + i];
                     if (PATH && (i == 1 || i == 2) && (j == 1 || j == 2)) {
                         const double g12 = gam[N * NCK + 12], g13 = gam[N * NCK + 13], a0 = hc[N * 2], a1 = hc[N * 2 + 1];
@@ -609,14 +620,14 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 // entries of G the track rows touch: (n,n) -> 1, (n,psi) -> 2, (psi,psi) -> 3
                 const int hsel = (lane < 55 && gi == 1 && gj == 1) ? 1 : (lane < 55 && gi + gj == 3 && gi * gj == 2) ? 2 : (lane < 55 && gi == 2 && gj == 2) ? 3 : 0;
                 const int ci = (gi < 8) ? gi : 64 + (gi - 8), si = (gi < 8) ? 8 : 2;      // column gi of [A B] in a record
-                double regH = a.Hs[((N - 1) * 10 + gi) * 10 + gj];
-                double rc0i = a.CD[((N - 1) * 2 + 0) * 10 + gi], rc0j = a.CD[((N - 1) * 2 + 0) * 10 + gj];
-                double rc1i = a.CD[((N - 1) * 2 + 1) * 10 + gi], rc1j = a.CD[((N - 1) * 2 + 1) * 10 + gj];
+                double regH = HS(N - 1, gi, gj);
+                double rc0i = CDV(N - 1, 0, gi), rc0j = CDV(N - 1, 0, gj);
+                double rc1i = CDV(N - 1, 1, gi), rc1j = CDV(N - 1, 1, gj);
                 // second product of the W phase: lanes 0..15 -> B part of W, lanes 16..23 -> P_{k+1} rb_k
                 const int i2 = (lane < 16) ? (lane >> 1) : ((lane < 24) ? lane - 16 : 0);
                 stream_sweep<-1, 4>(linb, stage2, N, lane, [&](int k, const double *AB) {
                     const double Hk = regH, c0i = rc0i, c0j = rc0j, c1i = rc1i, c1j = rc1j;
-                    if (k > 0) {
+                    if (!UNI && k > 0) {        // stage-dependent data: this lane's entries, fetched one stage ahead
                         regH = a.Hs[((k - 1) * 10 + gi) * 10 + gj];
                         rc0i = a.CD[((k - 1) * 2 + 0) * 10 + gi]; rc0j = a.CD[((k - 1) * 2 + 0) * 10 + gj];
                         rc1i = a.CD[((k - 1) * 2 + 1) * 10 + gi]; rc1j = a.CD[((k - 1) * 2 + 1) * 10 + gj];
@@ -895,15 +906,22 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M;
     const int N = h->N, NS = h->NS;
     const int nck = h->path_on ? 14 : 12;
-    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100);
+    const int uni = h->uniform_H && h->uniform_CD;
+    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100 +
+                                         (uni ? 20 + (h->path_on ? 0 : 200) : 0));
     if (lds > 160 * 1024) return 1;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
     a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
     const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
-#define LAUNCH_QP(NS_, NO_, PT_)                                                                                         \
-    do {                                                                                                                 \
-        (void)hipFuncSetAttribute((const void *)k_qp_wave<NS_, NO_, PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_qp_wave<NS_, NO_, PT_>), dim3(h->B), dim3(64), lds, h->stream, a);                         \
+#define LAUNCH_QP(NS_, NO_, PT_)                                                                                          \
+    do {                                                                                                                  \
+        if (uni) {                                                                                                        \
+            (void)hipFuncSetAttribute((const void *)k_qp_wave<NS_, NO_, PT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_qp_wave<NS_, NO_, PT_, 1>), dim3(h->B), dim3(64), lds, h->stream, a);                   \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void *)k_qp_wave<NS_, NO_, PT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_qp_wave<NS_, NO_, PT_, 0>), dim3(h->B), dim3(64), lds, h->stream, a);                   \
+        }                                                                                                                 \
     } while (0)
     if (!h->path_on) {
         if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0, 0);

@@ -386,3 +386,35 @@ def test_track_rows_rti_steps_match_oracle(track, model, soft, width):
         sl = s.get_slacks()
         assert np.all(sl[:, :, :12] == 0.0) and np.all(sl[:, 0] == 0.0)
         assert sl[:, 1:, 14 + 12:].max() > 1e-3     # some footprint is outside the narrow track and pays for it
+
+
+def test_stage_dependent_weights_and_rows_match_oracle(track):
+    """Per-stage W_k and per-stage general rows: the QP kernel's path WITHOUT the stage-invariant data in LDS."""
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    B = 40
+    ocp = make_ocp()
+    solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    d = solver.data
+    scale = 1.0 + 0.02 * np.arange(N)
+    d.W = d.W * scale[:, None, None]
+    solver.set_weights(d.W, d.W_e)
+    d.D = d.D * (1.0 + 0.01 * np.arange(N))[:, None, None]          # rows u*(1+eps_k) - x[6:8]
+    solver._push_bounds()
+    P = orc.OracleProblem(d.as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, B, seed=31)
+    solver.set_x0(x0); solver.init_guess()
+    x, u = solver.get_x(), solver.get_u()
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+    solver.set_yref(yref); solver.set_yref_e(yref_e); solver.set_multipliers(None, None)
+    status = solver.solve()
+    out = P.rti_step(x, u, x0, yref, yref_e)
+    np.testing.assert_array_equal(status, out["status"])
+    np.testing.assert_array_equal(solver.get_qp_iter(), out["qp_iter"])
+    ok = status == 0
+    assert ok.sum() >= 0.9 * B
+    assert _rel(solver.get_x()[ok], x[ok]) < 1e-7 and _rel(solver.get_u()[ok], u[ok]) < 1e-7     # tolerance 1e-7 relative
+    assert _rel(solver.get_residuals(), out["res"]) < 1e-9
+    solver.free()
