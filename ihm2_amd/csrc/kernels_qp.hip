@@ -109,16 +109,35 @@ __device__ __forceinline__ double sum8(double v)
     return v;
 }
 
+// Sum over the 8 lanes {w, w+8, ..., w+56} that share the position w within their group of 8: DPP row_ror:8 inside the 16-lane
+// row, then the gfx950 row / half swaps (v_permlane16_swap, v_permlane32_swap: with both operands equal the two results are
+// "mine" and "the partner's", so their sum is the butterfly step).  Every lane of the class gets the total; no LDS involved.
+__device__ __forceinline__ double sum_stride8(double v)
+{
+    v += dpp_mov<0x128>(v);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b16[0], a16[0]) + __hiloint2double(b16[1], a16[1]);
+    lo = __double2loint(v); hi = __double2hiint(v);
+    auto a32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b32[0], a32[0]) + __hiloint2double(b32[1], a32[1]);
+}
+
 // Ring of D coalesced 512-byte loads running D-1 stages ahead of a sequential sweep over a (N,64) array.
 // DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  body(k, value of element `lane` of row k).
+// The element a lane takes alternates with the step: e_even on steps 0, 2, ... and e_odd on steps 1, 3, ... (D is even);
+// body(k, value, odd).
 template <int DIR, int D, typename F>
-__device__ __forceinline__ void stream_rows(const double *rows, int N, int lane, F &&body)
+__device__ __forceinline__ void stream_rows(const double *rows, int N, int e_even, int e_odd, F &&body)
 {
+    static_assert(D % 2 == 0, "the element index alternates with the step parity");
     double r[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const int sd = min(d, N - 1);
-        r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sd : sd) * 64 + lane];
+        r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sd : sd) * 64 + ((d & 1) ? e_odd : e_even)];
     }
     for (int s0 = 0; s0 < N; s0 += D) {
 #pragma unroll
@@ -127,8 +146,8 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int lane,
             const int k = (DIR < 0) ? N - 1 - s : s;
             const double v = r[d];
             const int sn = min(s + D, N - 1);          // unconditional, clamped (see stream_sweep)
-            r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sn : sn) * 64 + lane];
-            if (s < N) body(k, v);
+            r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sn : sn) * 64 + ((d & 1) ? e_odd : e_even)];
+            if (s < N) body(k, v, (d & 1) != 0);
         }
     }
 }
@@ -705,14 +724,23 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             WSYNC();
 /*@S:7*/
-            // ... then one multiply + an 8-lane DPP sum per stage: lane (j, l) holds M_k[l][j]
+            // ... then the recursion itself, entirely in registers.  A lane is (g, w) = (lane >> 3, lane & 7).  The contraction runs
+            // over w inside the group on even steps (result: one value per group g) and over g across the groups on odd steps
+            // (result: one value per position w), so the output of a step is already laid out as the input of the next:
+            //   even: lane holds M[w][g], q_w = Prb_k[w] + p_{k+1}[w] -> p_k[g] ;  odd: lane holds M[g][w], q_g -> p_k[w]
             {
-                const int j = lane >> 3, l = lane & 7;
-                stream_rows<-1, 8>(Mg, N, (l << 3) | j, [&](int k, double m) {
-                    const double t = sum8(m * (Prb[k * 8 + l] + pv[(k + 1) * 8 + l]));
-                    if (l == 0) pv[k * 8 + j] += t;
-                    WSYNC();
+                const int g = lane >> 3, w = lane & 7;
+                double pw = pv[N * 8 + w], pg = 0.0;
+                stream_rows<-1, 8>(Mg, N, (w << 3) | g, lane, [&](int k, double m, bool odd) {
+                    if (!odd) {
+                        pg = pv[k * 8 + g] + sum8(m * (Prb[k * 8 + w] + pw));
+                        if (w == 0) pv[k * 8 + g] = pg;
+                    } else {
+                        pw = pv[k * 8 + w] + sum_stride8(m * (Prb[k * 8 + g] + pg));
+                        if (g == 0) pv[k * 8 + w] = pw;
+                    }
                 });
+                WSYNC();
             }
 /*@S:8*/
             // feed-forward terms kff_k = Guu^-1 (gt_u + B'(P_{k+1} rb_k + p_{k+1})) and the affine part
@@ -740,14 +768,21 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             WSYNC();
 
 /*@S:9*/
-            // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k ; lane (i, l) holds M_k[i][l] ----
+            // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k, same alternating register layout ----
+            //   even: lane holds M[g][w], dx_k[w] -> dx_{k+1}[g] ;  odd: lane holds M[w][g], dx_k[g] -> dx_{k+1}[w]
             {
-                const int i = lane >> 3, l = lane & 7;
-                stream_rows<+1, 8>(Mg, N, lane, [&](int k, double m) {
-                    const double t = sum8(m * dz[k * 10 + l]);
-                    if (l == 0) dz[(k + 1) * 10 + i] += t;
-                    WSYNC();
+                const int g = lane >> 3, w = lane & 7;
+                double dxw = dz[w], dxg = 0.0;
+                stream_rows<+1, 8>(Mg, N, lane, (w << 3) | g, [&](int k, double m, bool odd) {
+                    if (!odd) {
+                        dxg = dz[(k + 1) * 10 + g] + sum8(m * dxw);
+                        if (w == 0) dz[(k + 1) * 10 + g] = dxg;
+                    } else {
+                        dxw = dz[(k + 1) * 10 + w] + sum_stride8(m * dxg);
+                        if (g == 0) dz[(k + 1) * 10 + w] = dxw;
+                    }
                 });
+                WSYNC();
             }
 /*@S:10*/
             // inputs and costate steps of all stages in parallel
