@@ -127,27 +127,32 @@ __device__ __forceinline__ double sum_stride8(double v)
 
 // Ring of D coalesced 512-byte loads running D-1 stages ahead of a sequential sweep over a (N,64) array.
 // DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  body(k, value of element `lane` of row k).
-// The element a lane takes alternates with the step: e_even on steps 0, 2, ... and e_odd on steps 1, 3, ... (D is even);
-// body(k, value, odd).
-template <int DIR, int D, typename F>
-__device__ __forceinline__ void stream_rows(const double *rows, int N, int e_even, int e_odd, F &&body)
+// The element a lane takes alternates with the step: e_even on steps 0, 2, ... and e_odd on steps 1, 3, ... (D is even).
+// pre(k, odd, x0, x1) fetches the LDS operands of a step DL steps ahead of its use (the body's own LDS stores would otherwise
+// pin every LDS load behind them -- the compiler cannot see that the addresses differ -- and put an LDS latency on the
+// recursion chain);  body(k, value, odd, x0, x1).
+template <int DIR, int D, int DL, typename P, typename F>
+__device__ __forceinline__ void stream_rows(const double *rows, int N, int e_even, int e_odd, P &&pre, F &&body)
 {
-    static_assert(D % 2 == 0, "the element index alternates with the step parity");
-    double r[D];
+    static_assert(D % 2 == 0 && DL % 2 == 0 && D % DL == 0, "the element index alternates with the step parity");
+    double r[D], x0[DL], x1[DL];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const int sd = min(d, N - 1);
         r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sd : sd) * 64 + ((d & 1) ? e_odd : e_even)];
+        if (d < DL) pre((DIR < 0) ? N - 1 - sd : sd, (d & 1) != 0, x0[d], x1[d]);
     }
     for (int s0 = 0; s0 < N; s0 += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const int s = s0 + d;
             const int k = (DIR < 0) ? N - 1 - s : s;
-            const double v = r[d];
+            const double v = r[d], y0 = x0[d % DL], y1 = x1[d % DL];
             const int sn = min(s + D, N - 1);          // unconditional, clamped (see stream_sweep)
             r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sn : sn) * 64 + ((d & 1) ? e_odd : e_even)];
-            if (s < N) body(k, v, (d & 1) != 0);
+            const int sl = min(s + DL, N - 1);
+            pre((DIR < 0) ? N - 1 - sl : sl, (d & 1) != 0, x0[d % DL], x1[d % DL]);
+            if (s < N) body(k, v, (d & 1) != 0, y0, y1);
         }
     }
 }
@@ -731,15 +736,17 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             {
                 const int g = lane >> 3, w = lane & 7;
                 double pw = pv[N * 8 + w], pg = 0.0;
-                stream_rows<-1, 8>(Mg, N, (w << 3) | g, lane, [&](int k, double m, bool odd) {
-                    if (!odd) {
-                        pg = pv[k * 8 + g] + sum8(m * (Prb[k * 8 + w] + pw));
-                        if (w == 0) pv[k * 8 + g] = pg;
-                    } else {
-                        pw = pv[k * 8 + w] + sum_stride8(m * (Prb[k * 8 + g] + pg));
-                        if (g == 0) pv[k * 8 + w] = pw;
-                    }
-                });
+                stream_rows<-1, 8, 4>(Mg, N, (w << 3) | g, lane,
+                    [&](int k, bool odd, double &prb, double &base) { prb = Prb[k * 8 + (odd ? g : w)]; base = pv[k * 8 + (odd ? w : g)]; },
+                    [&](int k, double m, bool odd, double prb, double base) {
+                        if (!odd) {
+                            pg = base + sum8(m * (prb + pw));
+                            if (w == 0) pv[k * 8 + g] = pg;
+                        } else {
+                            pw = base + sum_stride8(m * (prb + pg));
+                            if (g == 0) pv[k * 8 + w] = pw;
+                        }
+                    });
                 WSYNC();
             }
 /*@S:8*/
@@ -773,15 +780,17 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             {
                 const int g = lane >> 3, w = lane & 7;
                 double dxw = dz[w], dxg = 0.0;
-                stream_rows<+1, 8>(Mg, N, lane, (w << 3) | g, [&](int k, double m, bool odd) {
-                    if (!odd) {
-                        dxg = dz[(k + 1) * 10 + g] + sum8(m * dxw);
-                        if (w == 0) dz[(k + 1) * 10 + g] = dxg;
-                    } else {
-                        dxw = dz[(k + 1) * 10 + w] + sum_stride8(m * dxg);
-                        if (g == 0) dz[(k + 1) * 10 + w] = dxw;
-                    }
-                });
+                stream_rows<+1, 8, 4>(Mg, N, lane, (w << 3) | g,
+                    [&](int k, bool odd, double &c, double &unused) { c = dz[(k + 1) * 10 + (odd ? w : g)]; unused = 0.0; },
+                    [&](int k, double m, bool odd, double c, double) {
+                        if (!odd) {
+                            dxg = c + sum8(m * dxw);
+                            if (w == 0) dz[(k + 1) * 10 + g] = dxg;
+                        } else {
+                            dxw = c + sum_stride8(m * dxg);
+                            if (g == 0) dz[(k + 1) * 10 + w] = dxw;
+                        }
+                    });
                 WSYNC();
             }
 /*@S:10*/
