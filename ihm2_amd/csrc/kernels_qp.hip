@@ -62,35 +62,8 @@ struct QpArgs {
 
 __device__ __forceinline__ bool fin(double v) { return fabs(v) < INF_BOUND; }
 
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ double wave_min(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-// NaN-propagating max (fmax drops NaNs): used where a NaN must surface in the residual
-__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
-__device__ __forceinline__ double wave_nanmax(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = nanmax(v, __shfl_xor(v, o));
-    return v;
-}
-
-// Sum over aligned groups of 8 consecutive lanes with DPP moves (VALU speed, no LDS crossbar):
-// quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror.  Every lane of the group gets the total.
+// Lane exchanges at VALU speed (no LDS crossbar): DPP moves inside a 16-lane row, v_permlane16_swap / v_permlane32_swap
+// (gfx950) across rows and halves.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
@@ -101,6 +74,33 @@ __device__ __forceinline__ double dpp_mov(double v)
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// Butterfly over all 64 lanes: xor 1, xor 2 (quad_perm), mirror inside 8 (row_half_mirror), rotate by 8 inside 16 (row_ror:8),
+// then the row and half swaps -- with both operands equal their two results are "mine" and "the partner's".
+template <typename OP>
+__device__ __forceinline__ double wave_reduce(double v, OP op)
+{
+    v = op(v, dpp_mov<0xB1>(v));
+    v = op(v, dpp_mov<0x4E>(v));
+    v = op(v, dpp_mov<0x141>(v));
+    v = op(v, dpp_mov<0x128>(v));
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = op(__hiloint2double(b16[0], a16[0]), __hiloint2double(b16[1], a16[1]));
+    lo = __double2loint(v); hi = __double2hiint(v);
+    auto a32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return op(__hiloint2double(b32[0], a32[0]), __hiloint2double(b32[1], a32[1]));
+}
+// NaN-propagating max (fmax drops NaNs): used where a NaN must surface in the residual
+__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce(v, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce(v, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double wave_nanmax(double v) { return wave_reduce(v, [](double a, double b) { return nanmax(a, b); }); }
+
+// Sum over aligned groups of 8 consecutive lanes with DPP moves (VALU speed, no LDS crossbar):
+// quad_perm(1,0,3,2), quad_perm(2,3,0,1), row_half_mirror.  Every lane of the group gets the total.
 __device__ __forceinline__ double sum8(double v)
 {
     v += dpp_mov<0xB1>(v);
