@@ -574,7 +574,8 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
         if (it >= a.iter_max) { qstatus = 1; break; }
         WSYNC();
 
-        double alpha = 1.0, sigma = 0.0;
+        // separate step lengths for the primal (z, t, s) and the dual (pi, lam, lam_s) variables, as HPIPM's split_step
+        double alpha = 1.0, alpha_d = 1.0, sigma = 0.0;
         for (int pass = 0; pass < 2; pass++) {
 /*@S:4*/
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
 /*@S:11*/
             // ---- slack / multiplier steps, step length ----
-            double amax = 1.0, mu_aff = 0.0;
+            double amax = 1.0, amax_d = 1.0, mu_aff = 0.0;
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
                 dlam_l[r] = dlam_u[r] = dt_l[r] = dt_u[r] = 0.0;
@@ -841,9 +842,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     so_ds[q] = dsv; so_dls[q] = dlsv;
                     if (al) { dt_l[r] = dtv; dlam_l[r] = dlv; } else { dt_u[r] = dtv; dlam_u[r] = dlv; }
                     if (dsv < 0.0) amax = fmin(amax, -so_s[q] / dsv);
-                    if (dlsv < 0.0) amax = fmin(amax, -so_ls[q] / dlsv);
+                    if (dlsv < 0.0) amax_d = fmin(amax_d, -so_ls[q] / dlsv);
                     if (dtv < 0.0) amax = fmin(amax, -tt / dtv);
-                    if (dlv < 0.0) amax = fmin(amax, -lm / dlv);
+                    if (dlv < 0.0) amax_d = fmin(amax_d, -lm / dlv);
                     continue;
                 }
                 if (fin(s_dl[r])) {
@@ -851,49 +852,49 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     dt_l[r] = drz + rd_l[r];
                     dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) / t_l[r];
                     if (dt_l[r] < 0.0) amax = fmin(amax, -t_l[r] / dt_l[r]);
-                    if (dlam_l[r] < 0.0) amax = fmin(amax, -lam_l[r] / dlam_l[r]);
+                    if (dlam_l[r] < 0.0) amax_d = fmin(amax_d, -lam_l[r] / dlam_l[r]);
                 }
                 if (fin(s_du[r])) {
                     const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + dla_u[r] * dta_u[r] - mu_t;
                     dt_u[r] = -drz + rd_u[r];
                     dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) / t_u[r];
                     if (dt_u[r] < 0.0) amax = fmin(amax, -t_u[r] / dt_u[r]);
-                    if (dlam_u[r] < 0.0) amax = fmin(amax, -lam_u[r] / dlam_u[r]);
+                    if (dlam_u[r] < 0.0) amax_d = fmin(amax_d, -lam_u[r] / dlam_u[r]);
                 }
             }
-            amax = wave_min(amax);
+            amax = wave_min(amax); amax_d = wave_min(amax_d);
             if (pass == 0) {
-                if (a.m_act == 0) { alpha = 1.0; break; }
+                if (a.m_act == 0) { alpha = alpha_d = 1.0; break; }
 #pragma unroll
                 for (int r = 0; r < NSLOT; r++) {
                     dla_l[r] = dlam_l[r]; dla_u[r] = dlam_u[r]; dta_l[r] = dt_l[r]; dta_u[r] = dt_u[r];
                     if (s_kc[r] < 0) continue;
-                    if (fin(s_dl[r])) mu_aff += (lam_l[r] + amax * dlam_l[r]) * (t_l[r] + amax * dt_l[r]);
-                    if (fin(s_du[r])) mu_aff += (lam_u[r] + amax * dlam_u[r]) * (t_u[r] + amax * dt_u[r]);
+                    if (fin(s_dl[r])) mu_aff += (lam_l[r] + amax_d * dlam_l[r]) * (t_l[r] + amax * dt_l[r]);
+                    if (fin(s_du[r])) mu_aff += (lam_u[r] + amax_d * dlam_u[r]) * (t_u[r] + amax * dt_u[r]);
                     if (IS_SOFT(r)) {
                         const int q = r < NSOFT ? r : 0;
                         so_pa[q] = so_dls[q] * so_ds[q];
-                        mu_aff += (so_ls[q] + amax * so_dls[q]) * (so_s[q] + amax * so_ds[q]);
+                        mu_aff += (so_ls[q] + amax_d * so_dls[q]) * (so_s[q] + amax * so_ds[q]);
                     }
                 }
                 mu_aff = wave_sum(mu_aff) * inv_m;
                 const double ratio = (mu > 0.0) ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
             } else {
-                alpha = fmin(1.0, 0.995 * amax);
+                alpha = fmin(1.0, 0.995 * amax); alpha_d = fmin(1.0, 0.995 * amax_d);
             }
             WSYNC();
         }
 /*@S:12*/
-        if (alpha < 1e-12) { qstatus = 2; break; }
+        if (fmin(alpha, alpha_d) < 1e-12) { qstatus = 2; break; }
         for (int e = lane; e < NS * 10; e += 64) z[e] = fma(alpha, dz[e], z[e]);
-        for (int e = lane; e < NS * 8; e += 64) pi[e] = fma(alpha, pv[e], pi[e]);
+        for (int e = lane; e < NS * 8; e += 64) pi[e] = fma(alpha_d, pv[e], pi[e]);
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
-            if (fin(s_dl[r])) { lam_l[r] = fma(alpha, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
-            if (fin(s_du[r])) { lam_u[r] = fma(alpha, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
-            if (IS_SOFT(r)) { const int q = r < NSOFT ? r : 0; so_s[q] = fma(alpha, so_ds[q], so_s[q]); so_ls[q] = fma(alpha, so_dls[q], so_ls[q]); }
+            if (fin(s_dl[r])) { lam_l[r] = fma(alpha_d, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
+            if (fin(s_du[r])) { lam_u[r] = fma(alpha_d, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
+            if (IS_SOFT(r)) { const int q = r < NSOFT ? r : 0; so_s[q] = fma(alpha, so_ds[q], so_s[q]); so_ls[q] = fma(alpha_d, so_dls[q], so_ls[q]); }
         }
         WSYNC();
     }

@@ -297,7 +297,8 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
                 for (int j = 0; j < NZ; j++) w.Ht[k][a2 * NZ + j] += gam * r[a2] * r[j];
         }
         /* ---- predictor (sigma = 0), then corrector ---- */
-        double alpha = 1.0, sigma = 0.0;
+        /* separate step lengths for the primal (z, t, s) and the dual (pi, lam, lam_s) variables, as HPIPM's split_step */
+        double alpha = 1.0, sigma = 0.0, alpha_d = 1.0;
         for (int pass = 0; pass < 2; pass++) {
             const double mu_target = fmax(sigma * mu, mu_floor); /* never aim below the tolerance */
             memcpy(gt, rg, sizeof(double) * NS * NZ);
@@ -317,7 +318,7 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
             riccati_backward(&w, pass == 0, gt, rb, p, kff);
             riccati_forward(&w, rb, p, kff, dz, dpi);
             /* slack / multiplier steps and the largest feasible step */
-            double amax = 1.0;
+            double amax = 1.0, amax_d = 1.0;
             for (int k = 0; k < NS; k++)
                 for (int c = 0; c < NC; c++) {
                     double drz = 0;
@@ -334,40 +335,40 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
                     ds[i] = -(rs[i] + c1 + c2) / D - gam / D * y;
                     dlams[i] = -(rm2[i] + lams[i] * ds[i]) / s[i];
                     if (ds[i] < 0) amax = fmin(amax, -s[i] / ds[i]);
-                    if (dlams[i] < 0) amax = fmin(amax, -lams[i] / dlams[i]);
+                    if (dlams[i] < 0) amax_d = fmin(amax_d, -lams[i] / dlams[i]);
                 }
                 dt[i] = y + ds[i] + rd[i];
                 dlam[i] = -(rm[i] + lam[i] * dt[i]) / t[i];
                 if (dt[i] < 0) amax = fmin(amax, -t[i] / dt[i]);
-                if (dlam[i] < 0) amax = fmin(amax, -lam[i] / dlam[i]);
+                if (dlam[i] < 0) amax_d = fmin(amax_d, -lam[i] / dlam[i]);
             }
             if (pass == 0) {
                 double mu_aff = 0;
                 for (int i = 0; i < NI; i++) {
                     if (!act[i]) continue;
-                    mu_aff += (lam[i] + amax * dlam[i]) * (t[i] + amax * dt[i]);
-                    if (soft[i]) mu_aff += (lams[i] + amax * dlams[i]) * (s[i] + amax * ds[i]);
+                    mu_aff += (lam[i] + amax_d * dlam[i]) * (t[i] + amax * dt[i]);
+                    if (soft[i]) mu_aff += (lams[i] + amax_d * dlams[i]) * (s[i] + amax * ds[i]);
                 }
                 if (m_act > 0) mu_aff /= m_act;
                 double ratio = (mu > 0) ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
                 memcpy(dlam_a, dlam, sizeof(double) * NI); memcpy(dt_a, dt, sizeof(double) * NI);
                 memcpy(dlams_a, dlams, sizeof(double) * NI); memcpy(ds_a, ds, sizeof(double) * NI);
-                if (m_act == 0) { alpha = 1.0; break; } /* no inequalities: Newton step is exact */
+                if (m_act == 0) { alpha = alpha_d = 1.0; break; } /* no inequalities: Newton step is exact */
             } else {
-                alpha = fmin(1.0, 0.995 * amax);
+                alpha = fmin(1.0, 0.995 * amax); alpha_d = fmin(1.0, 0.995 * amax_d);
             }
         }
-        if (orc_debug) fprintf(stderr, "        sigma %.3e alpha %.6f\n", sigma, alpha);
-        if (alpha < 1e-12) { status = 2; break; }
+        if (orc_debug) fprintf(stderr, "        sigma %.3e alpha %.6f alpha_d %.6f\n", sigma, alpha, alpha_d);
+        if (fmin(alpha, alpha_d) < 1e-12) { status = 2; break; }
         for (int k = 0; k < NS; k++) {
             for (int j = 0; j < NZ; j++) z[k * NZ + j] += alpha * dz[k * NZ + j];
-            for (int i = 0; i < NX; i++) pi[k * NX + i] += alpha * dpi[k * NX + i];
+            for (int i = 0; i < NX; i++) pi[k * NX + i] += alpha_d * dpi[k * NX + i];
         }
         for (int i = 0; i < NI; i++)
             if (act[i]) {
-                lam[i] += alpha * dlam[i]; t[i] += alpha * dt[i];
-                if (soft[i]) { lams[i] += alpha * dlams[i]; s[i] += alpha * ds[i]; }
+                lam[i] += alpha_d * dlam[i]; t[i] += alpha * dt[i];
+                if (soft[i]) { lams[i] += alpha_d * dlams[i]; s[i] += alpha * ds[i]; }
             }
     }
 #undef SGN
