@@ -27,7 +27,7 @@ def _stanley_guess(P, track, x0, M=25):
 def test_sqp_iterations_reach_kkt_points(track):
     """Repeated full-step RTI iterations on a frozen problem: every instance that settles does so at
     a KKT point of the NLP (stationarity at rounding level relative to |grad| ~ 1e4, defects and
-    bound violation ~ 1e-13).  Undamped Gauss-Newton SQP on this non-convex problem may also enter
+    bound violation below the QP tolerance).  Undamped Gauss-Newton SQP on this non-convex problem may also enter
     a 2-cycle (rate-limited bang-bang steering); such instances are not counted, they only must
     stay finite with status 0."""
     ocp = make_ocp(qp_tol=1e-8, qp_solver_iter_max=60)
@@ -52,7 +52,7 @@ def test_sqp_iterations_reach_kkt_points(track):
     settled = final[:, 1] < 1e-10
     assert settled.sum() >= 3, final
     assert np.all(final[settled, 0] < 1e-8 * gscale), final[:, 0]     # stationarity
-    assert np.all(final[settled, 2] < 1e-10), final[:, 2]             # bound violation
+    assert np.all(final[settled, 2] < 1e-8), final[:, 2]              # bound violation <= qp_tol (slack residual of the IPM)
     assert np.all(final[settled, 3] < 1e-7 * gscale), final[:, 3]     # complementarity ~ qp_tol * |g|
     assert np.all(hist[6, settled, 1] < 1e-6 * hist[1, settled, 1])    # fast local contraction
     assert np.all(np.abs(x[:, 0] - x0) < 1e-9) and np.all(np.isfinite(x)) and np.all(np.isfinite(u))
