@@ -141,9 +141,7 @@ def main():
     solver.init_guess()
 
     def step():
-        solver.sim_advance(model=0, M_sim=M_SUB)
-        solver.prepare_step(S_TARGET)
-        solver.solve_async()
+        solver.step(S_TARGET, model=0, M_sim=M_SUB)      # plant + shift/ramp + one RTI iteration (ihm2mpc_step)
         return solver.get_u0()        # device -> host, synchronises the solver's stream
 
     def barrier():

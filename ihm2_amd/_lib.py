@@ -72,6 +72,7 @@ SYMBOLS = {
     "ihm2mpc_get_status_device": (C.c_int, [_H, C.c_void_p]),
     "ihm2mpc_sim_step": (C.c_int, [_H, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "ihm2mpc_sim_advance": (C.c_int, [_H, C.c_int32, C.c_int32]),
+    "ihm2mpc_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double]),
     "ihm2mpc_get_x0": (C.c_int, [_H, c_double_p]),
 }
 

@@ -136,6 +136,9 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     h->NS = cfg->N + 1;
     const size_t B = h->B, N = h->N, NS = h->NS;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&h->ev[i]));
 #define DA(p, n) if (dalloc(&h->p, (n))) return -1
     DA(s_ref, (size_t)cfg->ntracks * cfg->nknots); DA(kappa_ref, (size_t)cfg->ntracks * cfg->nknots);
@@ -167,6 +170,9 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -481,7 +487,7 @@ int ihm2mpc_reinit_failed(ihm2mpc_handle *h, double v_ref_scale)
 int ihm2mpc_prepare_step(ihm2mpc_handle *h, double s_target)
 {
     CHECK_H(h);
-    ihm2_launch_prepare(h, s_target);
+    ihm2_launch_prepare(h, s_target, 3, h->stream);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -609,7 +615,7 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
     if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
-    ihm2_launch_sim(h, model, M_sim, xs, us, xn);
+    ihm2_launch_sim(h, model, M_sim, xs, us, xn, h->stream);
     HIP_TRY(hipGetLastError());
     return download(h, xn, x_next, NX);
 }
@@ -620,7 +626,31 @@ int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim)
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (M_sim < 1) return fail("M_sim must be >= 1");
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
-    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0);
+    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target)
+{
+    CHECK_H(h);
+    if (ready(h)) return -1;
+    if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
+    // The plant step and the reference ramp only feed the QP (through x0 and yref); the warm-start shift and the
+    // linearisation only need the previous iterate.  Two branches, joined in front of the QP kernel.
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream2);
+    ihm2_launch_prepare(h, s_target, 1, h->stream2);
+    HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
+    ihm2_launch_prepare(h, s_target, 2, h->stream);
+    ihm2_launch_linearize(h);
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+    HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }

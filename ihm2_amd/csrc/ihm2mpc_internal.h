@@ -28,6 +28,8 @@ struct ihm2mpc_handle {
     ihm2mpc_config cfg;
     int B, N, NS;
     hipStream_t stream;
+    hipStream_t stream2;           // plant + reference ramp of ihm2mpc_step run here, beside shift + linearisation
+    hipEvent_t ev_fork, ev_join;
     hipEvent_t ev[4];
     bool tracks_set, weights_set, bounds_set;
     bool uniform_H, uniform_CD;    // stage Hessians / general rows identical for all k < N (QP kernel keeps them in LDS)
@@ -78,8 +80,9 @@ struct ihm2mpc_handle {
 };
 
 // --- launchers (each defined in one .hip file) ---
-void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target);
+// mode: bit 0 = reference ramp (needs x0), bit 1 = warm-start shift
+void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits
-void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn);
+void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream);

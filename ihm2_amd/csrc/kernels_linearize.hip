@@ -186,9 +186,9 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
 }
 
-void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn)
+void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream)
 {
     const int blocks = (h->B + 63) / 64;
-    hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, h->stream, h->B, model, M_sim, h->cfg.dt,
+    hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
                        h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn);
 }

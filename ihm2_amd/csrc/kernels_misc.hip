@@ -14,17 +14,20 @@ namespace {
 // yref_j = [s0 + s_target j/N, 0 x 11], yref_e = [s0 + s_target, 0 x 7];
 // x_j <- x_{j+1}, u_j <- u_{j+1} (j < N-1); x_{N-1} <- x_N; u_{N-1} <- 0   (python/main.py:303-322)
 // One wavefront per instance; the old rows are read into registers before anything is overwritten.
-__global__ __launch_bounds__(64) void k_prepare(int B, int N, double s_target, const double *__restrict__ x0,
+__global__ __launch_bounds__(64) void k_prepare(int B, int N, double s_target, int mode, const double *__restrict__ x0,
                                                 double *__restrict__ x, double *__restrict__ u,
                                                 double *__restrict__ yref, double *__restrict__ yref_e)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
-    const double s0 = x0[(size_t)b * 8];
     double *xb = x + (size_t)b * (N + 1) * 8, *ub = u + (size_t)b * N * 2;
-    double *yb = yref + (size_t)b * N * 12, *ye = yref_e + (size_t)b * 8;
-    for (int e = lane; e < N * 12; e += 64) yb[e] = (e % 12 == 0) ? s0 + s_target * (e / 12) / N : 0.0;
-    if (lane < 8) ye[lane] = (lane == 0) ? s0 + s_target : 0.0;
+    if (mode & 1) {
+        const double s0 = x0[(size_t)b * 8];
+        double *yb = yref + (size_t)b * N * 12, *ye = yref_e + (size_t)b * 8;
+        for (int e = lane; e < N * 12; e += 64) yb[e] = (e % 12 == 0) ? s0 + s_target * (e / 12) / N : 0.0;
+        if (lane < 8) ye[lane] = (lane == 0) ? s0 + s_target : 0.0;
+    }
+    if (!(mode & 2)) return;
     // shift: element e of stage j takes the value of stage j+1 (j < N-1); stage N-1 takes stage N
     const int nx = N * 8;                    // rows 0..N-1 are rewritten, row N stays
     for (int base = 0; base < nx; base += 64) {
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
 
 }  // namespace
 
-void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target)
+void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_prepare, dim3(h->B), dim3(64), 0, h->stream, h->B, h->N, s_target, h->x0, h->x, h->u, h->yref,
+    hipLaunchKernelGGL(k_prepare, dim3(h->B), dim3(64), 0, stream, h->B, h->N, s_target, mode, h->x0, h->x, h->u, h->yref,
                        h->yref_e);
 }
 

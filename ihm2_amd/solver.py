@@ -271,6 +271,11 @@ class BatchedOcpSolver:
         """x0 <- plant(x0, u0 of the last solve), on device."""
         _lib.check(self.lib.ihm2mpc_sim_advance(self._h, int(model), int(M_sim)))
 
+    def step(self, s_target: float, model: int = 0, M_sim: int = 100):
+        """One MiL iteration on the device: ``sim_advance`` + ``prepare_step`` + one RTI iteration, with the plant step
+        overlapped with the linearisation.  Asynchronous; read results with ``get_u0`` / ``get_status``."""
+        _lib.check(self.lib.ihm2mpc_step(self._h, int(model), int(M_sim), float(s_target)))
+
     # ---- single stage of a single instance ----
     def _set_stage(self, i, stage, field, value):
         v = _f64(np.ravel(value))

@@ -168,6 +168,10 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
  * switch with IHM2MPC_MODEL_FDYN6U as the dynamic model) */
 int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim);
 int ihm2mpc_get_x0(ihm2mpc_handle *h, double *x0);
+/* one iteration of the MiL loop (python/main.py:476-517) on the device: sim_advance(model, M_sim), prepare_step(s_target) and
+ * one RTI iteration.  Same results as the three calls; the plant step and the reference ramp run beside the warm-start
+ * shift and the linearisation (they only meet in the QP), which hides the plant's latency. */
+int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target);
 
 #ifdef __cplusplus
 }

@@ -418,3 +418,26 @@ def test_stage_dependent_weights_and_rows_match_oracle(track):
     assert _rel(solver.get_x()[ok], x[ok]) < 1e-7 and _rel(solver.get_u()[ok], u[ok]) < 1e-7     # tolerance 1e-7 relative
     assert _rel(solver.get_residuals(), out["res"]) < 1e-9
     solver.free()
+
+
+def test_fused_step_equals_the_three_calls(track):
+    """ihm2mpc_step (plant and ramp on a second stream beside shift + linearisation) is bit-identical to
+    sim_advance + prepare_step + solve."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = 130
+    x0 = sample_x0(track, B, seed=8)
+    res = []
+    for fused in (False, True):
+        s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+        s.set_x0(x0); s.init_guess()
+        for _ in range(4):
+            if fused:
+                s.step(40.0, model=-1, M_sim=40)
+            else:
+                s.sim_advance(model=-1, M_sim=40); s.prepare_step(40.0); s.solve_async()
+        res.append((s.get_x0(), s.get_x(), s.get_u(), s.get_u0(), s.get_status(), s.get_qp_iter(), s.get_multipliers()[1]))
+        s.free()
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    assert (res[0][4] == 0).sum() >= 0.9 * B

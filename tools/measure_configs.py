@@ -54,10 +54,13 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
     plant = {"fkin6": 0, "fdyn6": 1, "fdyn6u": 2}[model]
 
     def step():
-        solver.sim_advance(model=plant, M_sim=25)
         if host_state:      # the state crosses the boundary as host buffers every step: D2H (B,8) + H2D (B,8) on top of the u0 readback
+            solver.sim_advance(model=plant, M_sim=25)
             solver.set_x0(solver.get_x0())
-        solver.prepare_step(40.0); solver.solve_async(); u0 = solver.get_u0()
+            solver.prepare_step(40.0); solver.solve_async()
+        else:
+            solver.step(40.0, model=plant, M_sim=25)
+        u0 = solver.get_u0()
         if recover:
             solver.reinit_failed()
         return u0
