@@ -976,6 +976,7 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
         else return 2;
     } else {
         if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 1);
+        else if (nsoft <= 3 && per_lane <= 8) LAUNCH_QP(8, 3, 1);
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 1);
         else return 2;
     }
