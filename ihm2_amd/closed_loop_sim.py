@@ -34,8 +34,15 @@ class SimModelVariant(Enum):
     KIN6_DYN6U = auto()
 
 
+    # Cartesian plants of the ROS simulation node (src/ihm2/src/sim_node.cpp:197-257; python/models.py:168-229, 310-452)
+    CART_KIN6 = auto()
+    CART_DYN6 = auto()
+    CART_KIN6_DYN6 = auto()   # the node's speed switch (v < v_dyn) and its "no reversing" clamp
+
+
 _PLANT_CODE = {SimModelVariant.KIN6: 0, SimModelVariant.DYN6: 1, SimModelVariant.KIN6_DYN6: -1, SimModelVariant.DYN6U: 2,
                SimModelVariant.KIN6_DYN6U: -2}
+_CART_CODE = {SimModelVariant.CART_KIN6: 3, SimModelVariant.CART_DYN6: 4, SimModelVariant.CART_KIN6_DYN6: -3}
 
 
 @dataclass
@@ -61,6 +68,83 @@ class Simulator:
     def advance(self) -> None:
         """x0 <- plant(x0, u0 of the last solve) without leaving the device."""
         self.controller.solver.sim_advance(model=_PLANT_CODE[self.variant], M_sim=self.config.num_steps)
+
+
+class CartesianSimulator:
+    """Plant in Cartesian coordinates as the ROS stack runs it: ``simulate(x_cart, u)`` advances ``(X, Y, phi, v_x, v_y, r, T,
+    delta)`` by one control period in 100 Hz plant steps (``sim_node.cpp:197-257``), ``project`` gives the controller its
+    Frenet state (``Track::project`` + ``mpc_control_node.cpp:142-157``).  The signature of ``new_python/simulator.py:25-40``
+    (``simulate(X, Y, phi, v_x, v_y, r, T, delta)``) is the unpacked form of ``simulate``."""
+
+    def __init__(self, controller: IHM2Controller, plan: MotionPlan, variant: SimModelVariant = SimModelVariant.CART_KIN6_DYN6,
+                 plant_dt: float = 0.01, num_steps: int = 10, v_dyn: float = 3.0, s_tol: float = 2.0):
+        if variant not in _CART_CODE:
+            raise NotImplementedError(f"Cartesian plant variant {variant.name}")
+        self.controller, self.variant = controller, variant
+        self.plant_dt, self.num_steps, self.v_dyn, self.s_tol = plant_dt, num_steps, v_dyn, s_tol
+        self.n_plant_steps = max(1, int(round(controller.dt / plant_dt)))
+        controller.solver.set_track_geometry(plan.X_ref, plan.Y_ref, plan.phi_ref)
+
+    def simulate(self, x_cart: np.ndarray, u: np.ndarray) -> np.ndarray:
+        return self.controller.solver.sim_step_cart(x_cart, u, model=_CART_CODE[self.variant], M_sim=self.num_steps, dt_sim=self.plant_dt,
+                                                    n_steps=self.n_plant_steps, v_dyn=self.v_dyn)
+
+    def project(self, x_cart: np.ndarray, s_guess: np.ndarray):
+        return self.controller.solver.project(x_cart, s_guess, self.s_tol)
+
+
+def frenet_to_cartesian(plan: MotionPlan, x_frenet: np.ndarray) -> np.ndarray:
+    """Cartesian state of a Frenet state on the (piecewise linear) centre line: position = point at s + n * normal."""
+    xf = np.atleast_2d(x_frenet)
+    s = xf[:, 0]
+    Xc = np.interp(s, plan.s_ref, plan.X_ref); Yc = np.interp(s, plan.s_ref, plan.Y_ref)
+    i = np.clip(np.searchsorted(plan.s_ref, s, side="right") - 1, 0, len(plan.s_ref) - 2)
+    th = np.arctan2(plan.Y_ref[i + 1] - plan.Y_ref[i], plan.X_ref[i + 1] - plan.X_ref[i])      # heading of the segment
+    out = xf.copy()
+    out[:, 0] = Xc - xf[:, 1] * np.sin(th)
+    out[:, 1] = Yc + xf[:, 1] * np.cos(th)
+    out[:, 2] = np.interp(s, plan.s_ref, np.unwrap(plan.phi_ref)) + xf[:, 2]
+    return out
+
+
+def run_closed_loop_cartesian(controller: IHM2Controller, simulator: CartesianSimulator, x_cart0: np.ndarray, s_guess0: np.ndarray,
+                              n_steps: int, lap_length: float | None = None) -> ClosedLoopResult:
+    """The ROS loop for a batch: project -> controller -> Cartesian plant.  ``ClosedLoopResult.x`` holds the FRENET states."""
+    B = controller.B
+    xc = np.asarray(x_cart0, dtype=np.float64).reshape(B, 8).copy()
+    sg = np.asarray(s_guess0, dtype=np.float64).reshape(B).copy()
+    xs, us, sts, runtimes, alive_hist = [], [], [], [], []
+    alive = np.ones(B, dtype=bool); finished = np.zeros(B, dtype=bool); lap_time = np.full(B, np.nan)
+    progress = np.zeros(B); s_prev = None
+    for i in range(n_steps):
+        alive_hist.append(alive.copy())
+        t0 = time.perf_counter()
+        xf, sg_new = simulator.project(xc, sg)
+        u = controller.compute_control(xf)
+        runtimes.append((time.perf_counter() - t0) * 1e3)
+        st = controller.last_status.copy()
+        alive &= ~(alive & ~np.isin(st, (0, 2)))
+        u = np.where(alive[:, None], np.nan_to_num(u), 0.0)
+        xn = simulator.simulate(xc, u)
+        alive &= ~(alive & np.any(np.isnan(xn), axis=1))
+        if s_prev is not None:
+            ds = xf[:, 0] - s_prev
+            if lap_length is not None:
+                ds = np.where(ds < -0.5 * lap_length, ds + lap_length, ds)     # s_guess wraps with fmod(., lap length)
+            progress += np.where(alive, ds, 0.0)
+        s_prev = xf[:, 0].copy()
+        xc = np.where(alive[:, None], xn, xc); sg = np.where(alive, sg_new, sg)
+        if lap_length is not None:
+            done = alive & (progress > lap_length)
+            lap_time[done] = (i + 1) * controller.dt
+            finished |= done; alive &= ~done
+        xs.append(xf.copy()); us.append(u); sts.append(st)
+        if not alive.any():
+            break
+    xs.append(xs[-1])
+    res = ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
+    res.progress = progress
+    return res
 
 
 class MultiModelSimulator(Simulator):

@@ -147,6 +147,8 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(CD, N * 20); DA(lg, N * 2); DA(ug, N * 2);
     DA(slot_kc, MAX_SLOTS); DA(slot_lb, MAX_SLOTS); DA(slot_ub, MAX_SLOTS); DA(slot_zw, MAX_SLOTS); DA(slot_Zw, MAX_SLOTS);
     DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2);
+    DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
+    DA(xc, B * 8); DA(s_guess, B);
     h->host_lb = new double[NS * NC]; h->host_ub = new double[NS * NC];
     h->host_sz = new double[NS * NLAM]; h->host_sZ = new double[NS * NLAM];
     for (size_t i = 0; i < NS * NC; i++) { h->host_lb[i] = -INFINITY; h->host_ub[i] = INFINITY; }
@@ -165,7 +167,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
                     h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
@@ -651,6 +653,81 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- Cartesian side of the ROS stack (N2 plants, N3 projection) ----
+int ihm2mpc_set_track_geometry(ihm2mpc_handle *h, const double *X_ref, const double *Y_ref, const double *phi_ref)
+{
+    CHECK_H(h);
+    if (!X_ref || !Y_ref || !phi_ref) return fail("null argument");
+    const size_t n = (size_t)h->cfg.ntracks * h->cfg.nknots;
+    if (upload_shared(h, X_ref, h->X_ref, n) || upload_shared(h, Y_ref, h->Y_ref, n) || upload_shared(h, phi_ref, h->phi_ref, n)) return -1;
+    h->geometry_set = true;
+    return 0;
+}
+
+static int check_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps)
+{
+    if (model != IHM2MPC_PLANT_KIN6 && model != IHM2MPC_PLANT_DYN6 && model != IHM2MPC_PLANT_ROS) return fail("unknown Cartesian plant %d", model);
+    if (M_sim < 1 || n_steps < 1) return fail("M_sim and n_steps must be >= 1");
+    if (!(dt_sim > 0.0)) return fail("dt_sim must be positive");
+    (void)h;
+    return 0;
+}
+
+int ihm2mpc_sim_step_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps, double v_dyn,
+                          const double *x, const double *u, double *x_next)
+{
+    CHECK_H(h);
+    if (!x || !u || !x_next) return fail("null argument");
+    if (check_cart(h, model, M_sim, dt_sim, n_steps)) return -1;
+    double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
+    if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
+    ihm2_launch_sim_cart(h, model, M_sim, dt_sim, n_steps, v_dyn, xs, us, xn, h->stream);
+    HIP_TRY(hipGetLastError());
+    return download(h, xn, x_next, NX);
+}
+
+int ihm2mpc_project(ihm2mpc_handle *h, const double *x_cart, double *s_guess, double s_tol, double *x_frenet)
+{
+    CHECK_H(h);
+    if (!x_cart || !s_guess || !x_frenet) return fail("null argument");
+    if (!h->tracks_set || !h->geometry_set) return fail("ihm2mpc_set_tracks / ihm2mpc_set_track_geometry have not been called");
+    if (!(s_tol > 0.0)) return fail("s_tol must be positive");
+    double *xs = h->scratch, *sg = h->scratch + (size_t)h->B * 8, *xf = h->scratch + (size_t)h->B * 9;
+    if (upload(h, x_cart, xs, NX) || upload(h, s_guess, sg, 1)) return -1;
+    ihm2_launch_project(h, s_tol, xs, sg, xf, h->stream);
+    HIP_TRY(hipGetLastError());
+    if (download(h, xf, x_frenet, NX)) return -1;
+    return download(h, sg, s_guess, 1);
+}
+
+int ihm2mpc_set_cart_state(ihm2mpc_handle *h, const double *x_cart, const double *s_guess)
+{
+    CHECK_H(h);
+    if (!x_cart || !s_guess) return fail("null argument");
+    if (upload(h, x_cart, h->xc, NX)) return -1;
+    return upload(h, s_guess, h->s_guess, 1);
+}
+
+int ihm2mpc_get_cart_state(ihm2mpc_handle *h, double *x_cart, double *s_guess)
+{
+    CHECK_H(h);
+    if (x_cart && download(h, h->xc, x_cart, NX)) return -1;
+    if (s_guess && download(h, h->s_guess, s_guess, 1)) return -1;
+    return 0;
+}
+
+int ihm2mpc_sim_advance_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps, double v_dyn, double s_tol)
+{
+    CHECK_H(h);
+    if (!h->tracks_set || !h->geometry_set) return fail("ihm2mpc_set_tracks / ihm2mpc_set_track_geometry have not been called");
+    if (check_cart(h, model, M_sim, dt_sim, n_steps)) return -1;
+    if (!(s_tol > 0.0)) return fail("s_tol must be positive");
+    ihm2_launch_sim_cart(h, model, M_sim, dt_sim, n_steps, v_dyn, h->xc, h->u0, h->xc, h->stream);
+    ihm2_launch_project(h, s_tol, h->xc, h->s_guess, h->x0, h->stream);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -57,6 +57,11 @@ struct ihm2mpc_handle {
     int path_on;
     double car_L, car_W, lh[NH], uh[NH];
     double *widths;                // (ntracks, 2) = (w_R, w_L), device
+    // Cartesian side (ROS stack): centre-line geometry per track, Cartesian plant state and projection guess per instance
+    bool geometry_set;
+    double *X_ref, *Y_ref, *phi_ref;   // (ntracks, nknots)
+    double *xc;                    // (B,8) (X, Y, phi, v_x, v_y, r, T, delta)
+    double *s_guess;               // (B)
 
     // ---- per-instance state, instance-major ----
     double *x;      // (B,NS,8)
@@ -86,3 +91,6 @@ void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_fail
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream);
+void ihm2_launch_sim_cart(ihm2mpc_handle *h, int model, int M, double dt, int n_steps, double v_dyn, const double *x, const double *u,
+                          double *xn, hipStream_t stream);
+void ihm2_launch_project(ihm2mpc_handle *h, double s_tol, const double *xc, double *s_guess, double *xf, hipStream_t stream);

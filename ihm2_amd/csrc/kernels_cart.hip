@@ -1,0 +1,211 @@
+// kernels_cart.hip -- the Cartesian side of the ROS stack, batched:
+//  * k_sim_cart : plant steps of the simulation node (src/ihm2/src/sim_node.cpp:197-257): kin6 below v_dyn, dyn6 above
+//                 (python/models.py:168-229, 310-452), RK4 x M per plant step, "no reversing" clamp;
+//  * k_project  : Track::project (src/ihm2/src/common/tracks.cpp:183-288) and the Frenet states of the control node
+//                 (src/ihm2/src/mpc_control_node.cpp:142-157).
+// One lane per instance: both are a few hundred dependent operations on 8 doubles, off the solver's critical path
+// (ihm2mpc_step runs the plant beside the linearisation).
+#include "ihm2mpc_internal.h"
+#include "model.hpp"
+
+using namespace ihm2;
+
+namespace {
+
+__device__ __forceinline__ double lat_pacejka_d(double alpha) { return lat_pacejka_t<double>(alpha); }
+
+// kin6: the fkin6 force model with Cartesian kinematics and r_dot = v_y_dot / l_R (python/models.py:226)
+__device__ inline void kin6_rhs(const double (&x)[8], double u_T, double u_delta, double (&f)[8])
+{
+    const double phi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
+    const double delta_dot = (u_delta - delta) * (1.0 / k_tdelta), T_dot = (u_T - T) * (1.0 / k_tT);
+    const double F_motor = k_Cm0 * T;
+    const double F_drag = -(k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x) * tanh(10.0 * v_x);
+    const double F_Rx = 0.5 * F_motor + F_drag, F_Fx = 0.5 * F_motor;
+    const double td = tan(delta);
+    const double q = 1.0 + k_rwd * k_rwd * td * td, iden = rsqrt(q);
+    const double sinbeta = k_rwd * td * iden, cosbeta = iden;
+    const double beta = atan(k_rwd * td);
+    const double beta_dot = k_rwd * (1.0 + td * td) / q * delta_dot;
+    const double v_dot = (F_Rx * cosbeta + F_Fx * cos(delta - beta)) * (1.0 / k_m);
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    const double v_y_dot = v_dot * sinbeta + beta_dot * v_x;
+    f[0] = v_x * cp - v_y * sp;
+    f[1] = v_x * sp + v_y * cp;
+    f[2] = r;
+    f[3] = v_dot * cosbeta - beta_dot * v_y;
+    f[4] = v_y_dot;
+    f[5] = v_y_dot * (1.0 / k_lR);
+    f[6] = T_dot;
+    f[7] = delta_dot;
+}
+
+// dyn6: 4-wheel Pacejka model in the body frame; the load transfer makes the tyre forces affine in (a_x, a_y): 2x2 solve
+__device__ inline void dyn6_rhs(const double (&x)[8], double u_T, double u_delta, double (&f)[8])
+{
+    const double phi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
+    double sd, cd;
+    sincos(delta, &sd, &cd);
+    const double F_down = 0.5 * k_Cdown * v_x * v_x;
+    const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track;
+    const double base = k_static_weight + 0.25 * F_down, hx = 0.5 * k_axle_track;
+    const double v_x_L = v_x - hx * r, v_x_R = v_x + hx * r, v_y_F = v_y + k_lF * r, v_y_R = v_y - k_lR * r;
+    const double glat0 = lat_pacejka_d(atan2(v_y_F, v_x_L) - delta), glat1 = lat_pacejka_d(atan2(v_y_F, v_x_R) - delta);
+    const double glat2 = lat_pacejka_d(atan2(v_y_R, v_x_L)), glat3 = lat_pacejka_d(atan2(v_y_R, v_x_R));
+    const double F_drag = -(k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x) * tanh(1000.0 * v_x);
+    const double td = tan(delta);
+    const double sinbeta = k_rwd * td * rsqrt(1.0 + k_rwd * k_rwd * td * td);
+    const double dtau = k_Ktv * (v_x * sinbeta * (1.0 / k_lR) - r);
+    const double denom = -k_m * k_g - 0.25 * F_down;
+    const double gm = k_Cm0 * (T - dtau) / denom, gp = k_Cm0 * (T + dtau) / denom;      // FL, RL = gm ; FR, RR = gp
+    const double cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;
+    const double cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;
+    const double cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
+    const double cz2 = -(gm * hx) - glat2 * k_lR, cz3 = gp * hx - glat3 * k_lR;
+    // m a_x = X0 + Xx a_x + Xy a_y ; m a_y = Y0 + Yx a_x + Yy a_y with F_z,k = -(base + sx_k cx a_x + sy_k cy a_y)
+    const double sumx = cx0 + cx1 + gm + gp, sumy = cy0 + cy1 + glat2 + glat3;
+    const double X0 = F_drag - sumx * base, Y0 = -(sumy * base);
+    const double Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
+    const double Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
+    const double a11 = k_m - Xx, a12 = -Xy, a21 = -Yx, a22 = k_m - Yy;
+    const double det = a11 * a22 - a12 * a21;
+    const double a_x = (X0 * a22 - a12 * Y0) / det, a_y = (a11 * Y0 - a21 * X0) / det;
+    const double lx = a_x * cx, ly = a_y * cy;
+    const double Mz = cz0 * -(base - lx + ly) + cz1 * -(base - lx - ly) + cz2 * -(base + lx + ly) + cz3 * -(base + lx - ly);
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    f[0] = v_x * cp - v_y * sp;
+    f[1] = v_x * sp + v_y * cp;
+    f[2] = r;
+    f[3] = a_x + v_y * r;
+    f[4] = a_y - v_x * r;
+    f[5] = Mz * (1.0 / k_Iz);
+    f[6] = (u_T - T) * (1.0 / k_tT);
+    f[7] = (u_delta - delta) * (1.0 / k_tdelta);
+}
+
+// n_steps plant steps of length dt (each RK4 x M); model 3 = kin6, 4 = dyn6, -3 = the node's speed switch + no reversing
+__global__ __launch_bounds__(64) void k_sim_cart(int B, int model, int M, double dt, int n_steps, double v_dyn, const double *xs,
+                                                 const double *__restrict__ us, double *xn)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)b * 8 + i];
+    const double u_T = us[(size_t)b * 2], u_d = us[(size_t)b * 2 + 1];
+    const double h = dt / M;
+    for (int step = 0; step < n_steps; step++) {
+        int mdl = model;
+        if (model == -3) mdl = (hypot(x[3], x[4]) < v_dyn) ? IHM2MPC_PLANT_KIN6 : IHM2MPC_PLANT_DYN6;
+        for (int m = 0; m < M; m++) {
+            double xacc[8], K[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+#pragma unroll 1
+            for (int st = 0; st < 4; st++) {
+                const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+                const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+                double X[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+                if (mdl == IHM2MPC_PLANT_KIN6) kin6_rhs(X, u_T, u_d, K);
+                else dyn6_rhs(X, u_T, u_d, K);
+#pragma unroll
+                for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = xacc[i];
+        }
+        if (model == -3 && (x[3] < 0.0 || (x[6] <= 0.1 && x[3] < 0.01))) { x[3] = 0.0; x[4] = 0.0; x[5] = 0.0; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = x[i];
+}
+
+__device__ __forceinline__ double wrap_to_pi(double x)
+{
+    double t = fmod(x + M_PI, 2.0 * M_PI);
+    if (t < 0.0) t += 2.0 * M_PI;
+    return t - M_PI;
+}
+// index of the last element <= x, -1 if x < v[0]
+__device__ inline int locate_index(const double *v, int n, double x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+__device__ __forceinline__ double angle3pt(double ax, double ay, double bx, double by, double cx, double cy)
+{
+    return wrap_to_pi(atan2(cy - by, cx - bx) - atan2(ay - by, ax - bx));
+}
+
+__global__ __launch_bounds__(64) void k_project(int B, int nk, double s_tol, const double *__restrict__ s_ref,
+                                                const double *__restrict__ X_ref, const double *__restrict__ Y_ref,
+                                                const double *__restrict__ phi_ref, const int32_t *__restrict__ track_id,
+                                                const double *__restrict__ xc, double *s_guess, double *xf)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int t = track_id[b];
+    const double *sr = s_ref + (size_t)t * nk, *Xr = X_ref + (size_t)t * nk, *Yr = Y_ref + (size_t)t * nk, *pr = phi_ref + (size_t)t * nk;
+    const double X = xc[(size_t)b * 8], Y = xc[(size_t)b * 8 + 1], sg = s_guess[b];
+    const double s_low = fmax(sg - s_tol, sr[0]), s_up = fmin(sg + s_tol, sr[nk - 1]);
+    int id_low = locate_index(sr, nk, s_low), id_up = locate_index(sr, nk, s_up);
+    if (id_low > 0) --id_low;
+    if (id_up < nk - 1) ++id_up;
+    const int nloc = id_up - id_low + 1;
+    int id_min = 0;
+    double best = INFINITY;
+    for (int i = 0; i < nloc; i++) {
+        const double dx = Xr[id_low + i] - X, dy = Yr[id_low + i] - Y, d = dx * dx + dy * dy;
+        if (d < best) { best = d; id_min = i; }
+    }
+    const int id_prev = (id_min == 0) ? nloc - 1 : id_min - 1;
+    const int id_next = (id_min == nloc - 1) ? 0 : id_min + 1;
+    const double mx = Xr[id_low + id_min], my = Yr[id_low + id_min];
+    const double px = Xr[id_low + id_prev], py = Yr[id_low + id_prev];
+    const double nx = Xr[id_low + id_next], ny = Yr[id_low + id_next];
+    const double angle_prev = fabs(angle3pt(mx, my, X, Y, px, py)), angle_next = fabs(angle3pt(mx, my, X, Y, nx, ny));
+    const bool use_prev = angle_prev > angle_next;
+    const double ax = use_prev ? px : mx, ay = use_prev ? py : my, bx = use_prev ? mx : nx, by = use_prev ? my : ny;
+    const double sa = use_prev ? sr[id_prev + id_low] : sr[id_min + id_low], sb = use_prev ? sr[id_min + id_low] : sr[id_next + id_low];
+    const double dx = bx - ax, dy = by - ay;
+    const double lambda = ((X - ax) * dx + (Y - ay) * dy) / (dx * dx + dy * dy);
+    const double s = sa + lambda * (sb - sa), Xp = ax + lambda * dx, Yp = ay + lambda * dy;
+    int ind = id_min + id_low;
+    if (ind > nk - 2) ind = nk - 2;
+    const double phi_p = pr[ind] + (pr[ind + 1] - pr[ind]) / (sr[ind + 1] - sr[ind]) * (s - sr[ind]);
+    const double rho = wrap_to_pi(phi_p);
+    const double psi = wrap_to_pi(wrap_to_pi(xc[(size_t)b * 8 + 2]) - rho);
+    const double e = hypot(Xp - X, Yp - Y);
+    double sr_, cr_;
+    sincos(rho, &sr_, &cr_);
+    const double tpr = (Y - Yp) * cr_ - (X - Xp) * sr_;
+    double *o = xf + (size_t)b * 8;
+    o[0] = s;
+    o[1] = e * (tpr > 0.0 ? 1.0 : -1.0);
+    o[2] = psi;
+#pragma unroll
+    for (int i = 3; i < 8; i++) o[i] = xc[(size_t)b * 8 + i];
+    s_guess[b] = fmod(s + xc[(size_t)b * 8 + 3] * 0.05, -sr[0]);
+}
+
+}  // namespace
+
+void ihm2_launch_sim_cart(ihm2mpc_handle *h, int model, int M, double dt, int n_steps, double v_dyn, const double *x, const double *u,
+                          double *xn, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_sim_cart, dim3((h->B + 63) / 64), dim3(64), 0, stream, h->B, model, M, dt, n_steps, v_dyn, x, u, xn);
+}
+
+void ihm2_launch_project(ihm2mpc_handle *h, double s_tol, const double *xc, double *s_guess, double *xf, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_project, dim3((h->B + 63) / 64), dim3(64), 0, stream, h->B, h->cfg.nknots, s_tol, h->s_ref, h->X_ref, h->Y_ref,
+                       h->phi_ref, h->track_id, xc, s_guess, xf);
+}

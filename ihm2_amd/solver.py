@@ -267,6 +267,38 @@ class BatchedOcpSolver:
         _lib.check(self.lib.ihm2mpc_sim_step(self._h, int(model), int(M_sim), _ptr(x), _ptr(u), _ptr(out)))
         return out
 
+    # ---- Cartesian side of the ROS stack (plants of sim_node.cpp, Track::project) ----
+    def set_track_geometry(self, X_ref, Y_ref, phi_ref):
+        """Centre line on the ``s_ref`` grid, ``(ntracks, nknots)`` each (the track-file columns of ``tracks.cpp:132-181``)."""
+        arrs = [_f64(np.atleast_2d(a), (self.ntracks, self.nknots), n) for a, n in ((X_ref, "X_ref"), (Y_ref, "Y_ref"), (phi_ref, "phi_ref"))]
+        _lib.check(self.lib.ihm2mpc_set_track_geometry(self._h, *[_ptr(a) for a in arrs]))
+
+    def sim_step_cart(self, x, u, model: int = -3, M_sim: int = 10, dt_sim: float = 0.01, n_steps: int = 5, v_dyn: float = 3.0):
+        """``n_steps`` plant steps of ``dt_sim`` under a constant ``u``; model 3 = kin6, 4 = dyn6, -3 = the node's switch."""
+        x = _f64(x, (self.B, NX), "x"); u = _f64(u, (self.B, NU), "u")
+        out = np.empty((self.B, NX))
+        _lib.check(self.lib.ihm2mpc_sim_step_cart(self._h, int(model), int(M_sim), float(dt_sim), int(n_steps), float(v_dyn), _ptr(x), _ptr(u), _ptr(out)))
+        return out
+
+    def project(self, x_cart, s_guess, s_tol: float = 2.0):
+        """Cartesian states ``(B,8)`` -> Frenet states ``(B,8)`` and the next projection guess ``(B,)``."""
+        xc = _f64(x_cart, (self.B, NX), "x_cart"); sg = _f64(s_guess, (self.B,), "s_guess").copy()
+        out = np.empty((self.B, NX))
+        _lib.check(self.lib.ihm2mpc_project(self._h, _ptr(xc), _ptr(sg), float(s_tol), _ptr(out)))
+        return out, sg
+
+    def set_cart_state(self, x_cart, s_guess):
+        _lib.check(self.lib.ihm2mpc_set_cart_state(self._h, _ptr(_f64(x_cart, (self.B, NX), "x_cart")), _ptr(_f64(s_guess, (self.B,), "s_guess"))))
+
+    def get_cart_state(self):
+        xc = np.empty((self.B, NX)); sg = np.empty(self.B)
+        _lib.check(self.lib.ihm2mpc_get_cart_state(self._h, _ptr(xc), _ptr(sg)))
+        return xc, sg
+
+    def sim_advance_cart(self, model: int = -3, M_sim: int = 10, dt_sim: float = 0.01, n_steps: int = 5, v_dyn: float = 3.0, s_tol: float = 2.0):
+        """On device: x_cart <- plant(x_cart, u0 of the last solve); x0 <- project(x_cart)."""
+        _lib.check(self.lib.ihm2mpc_sim_advance_cart(self._h, int(model), int(M_sim), float(dt_sim), int(n_steps), float(v_dyn), float(s_tol)))
+
     def sim_advance(self, model: int = 0, M_sim: int = 100):
         """x0 <- plant(x0, u0 of the last solve), on device."""
         _lib.check(self.lib.ihm2mpc_sim_advance(self._h, int(model), int(M_sim)))

@@ -173,6 +173,28 @@ int ihm2mpc_get_x0(ihm2mpc_handle *h, double *x0);
  * shift and the linearisation (they only meet in the QP), which hides the plant's latency. */
 int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target);
 
+/* ---- Cartesian side of the ROS stack ----
+ * Plants of the simulation node (src/ihm2/src/sim_node.cpp:197-257), state (X, Y, phi, v_x, v_y, r, T, delta): */
+#define IHM2MPC_PLANT_KIN6 3    /* python/models.py:168-229 */
+#define IHM2MPC_PLANT_DYN6 4    /* python/models.py:310-452 (implicit there; solved for xdot on device) */
+#define IHM2MPC_PLANT_ROS (-3)  /* kin6 while hypot(v_x, v_y) < v_dyn, else dyn6; no reversing (sim_node.cpp:200,246-250) */
+/* centre line of every track on the s_ref grid of ihm2mpc_set_tracks: X_ref, Y_ref, phi_ref (ntracks, nknots) -- the columns of
+ * the track file the C++ Track loads (src/ihm2/src/common/tracks.cpp:132-181) */
+int ihm2mpc_set_track_geometry(ihm2mpc_handle *h, const double *X_ref, const double *Y_ref, const double *phi_ref);
+/* n_steps plant steps of length dt_sim (the node: 0.01 s), each RK4 x M_sim, under a constant u; host (B,8),(B,2) -> (B,8) */
+int ihm2mpc_sim_step_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps, double v_dyn,
+                          const double *x, const double *u, double *x_next);
+/* Track::project (tracks.cpp:183-288) + the Frenet states of the control node (src/ihm2/src/mpc_control_node.cpp:142-157):
+ * x_cart (B,8) -> x_frenet (B,8) = (s, n, psi, v_x, v_y, r, T, delta); s_guess (B) in: centre of the search window of
+ * half-width s_tol (the node: 2.0), out: fmod(s + 0.05 v_x, lap length) */
+int ihm2mpc_project(ihm2mpc_handle *h, const double *x_cart, double *s_guess, double s_tol, double *x_frenet);
+/* device-resident Cartesian plant state for closed loops: sim_advance_cart = plant(x_cart, u0 of the last solve), then
+ * x0 <- project(x_cart) */
+int ihm2mpc_set_cart_state(ihm2mpc_handle *h, const double *x_cart, const double *s_guess);
+int ihm2mpc_get_cart_state(ihm2mpc_handle *h, double *x_cart, double *s_guess);
+int ihm2mpc_sim_advance_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps, double v_dyn,
+                             double s_tol);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,8 @@ extern "C" {
 
 /* FDYN6U: fdyn6 with every wheel's lateral force on its OWN slip angle; the reference crosses them (python/models.py:543-546,
  * quirk Q3), which makes the model open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s) */
-enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1, ORC_MODEL_FDYN6U = 2 };
+/* KIN6 / DYN6: the Cartesian plants of the ROS simulation node (python/models.py:168-229, 310-452), state (X, Y, phi, ...) */
+enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1, ORC_MODEL_FDYN6U = 2, ORC_MODEL_KIN6 = 3, ORC_MODEL_DYN6 = 4 };
 enum { ORC_INTEG_RK4 = 0 };
 
 typedef struct {
@@ -151,6 +152,14 @@ void orc_sim_step(const orc_problem *P, int B, int model, int M, const double *x
                   const int *track_id, double *xnext, int nthreads);
 
 int orc_num_threads(void);
+
+/* --- Cartesian side of the ROS stack (ihm2_oracle_track.c): projection on the track, Frenet states, plant step --- */
+void orc_project(const double *s_ref, const double *X_ref, const double *Y_ref, const double *phi_ref, int nk, double X,
+                 double Y, double s_guess, double s_tol, double *s_proj, double *X_proj, double *Y_proj, double *phi_proj);
+void orc_cart_to_frenet(int B, int ntracks, int nk, const double *s_ref, const double *X_ref, const double *Y_ref,
+                        const double *phi_ref, const int *track_id, const double *x_cart, double *s_guess, double s_tol,
+                        double *x_frenet);
+void orc_sim_step_cart(int B, int model, int M, double dt, double v_dyn, const double *x, const double *u, double *xnext);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,12 @@ static inline cplx cs_exp(cplx z) { double e = exp(creal(z)); return cs_make(e, 
 static inline cplx cs_sqrt(cplx z) { double r = sqrt(creal(z)); return cs_make(r, cimag(z) / (2.0 * r)); }
 /* atan2(y, x) with x > 0 (x is always smooth_abs_nonzero(.) > 0 at the call sites) */
 static inline cplx cs_atan2_pos(cplx y, cplx x) { return cs_atan(y / x); }
+/* general atan2 (any quadrant): d atan2(y, x) = (x dy - y dx) / (x^2 + y^2) */
+static inline cplx cs_atan2(cplx y, cplx x)
+{
+    double yr = creal(y), xr = creal(x);
+    return cs_make(atan2(yr, xr), (xr * cimag(y) - yr * cimag(x)) / (xr * xr + yr * yr));
+}
 
 /* python/utils.py:23-32 */
 static inline cplx cs_smooth_sgn(cplx x) { return cs_tanh(10.0 * x); }
@@ -227,9 +233,93 @@ static void fdyn6_cs(const cplx *x, const cplx *u, const double *s_ref, const do
     f[7] = (u_delta - delta) / t_delta;
 }
 
+/* ---- Cartesian plants of the ROS simulation node (src/ihm2/src/sim_node.cpp:197-257): x = (X, Y, phi, v_x, v_y, r, T, delta) ---- */
+/* kin6 (python/models.py:168-229): the fkin6 force model with Cartesian kinematics and r_dot = v_y_dot / l_R (:226) */
+static void kin6_cs(const cplx *x, const cplx *u, cplx *f)
+{
+    const double rwd = l_R / wheelbase;
+    cplx phi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
+    cplx delta_dot = (u[1] - delta) / t_delta, T_dot = (u[0] - T) / t_T;
+    cplx F_motor = C_m0 * T;
+    cplx F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * cs_smooth_sgn(v_x);
+    cplx F_Rx = 0.5 * F_motor + F_drag, F_Fx = 0.5 * F_motor;
+    cplx tandelta = cs_tan(delta);
+    cplx den = cs_sqrt(1.0 + rwd * rwd * tandelta * tandelta);
+    cplx beta = cs_atan(rwd * tandelta);
+    cplx sinbeta = rwd * tandelta / den, cosbeta = 1.0 / den;         /* :196-207, algebraic */
+    cplx beta_dot = rwd * (1.0 + tandelta * tandelta) / (1.0 + rwd * rwd * tandelta * tandelta) * delta_dot;
+    cplx v_dot = (F_Rx * cosbeta + F_Fx * cs_cos(delta - beta)) / m_;
+    cplx v_y_dot = v_dot * sinbeta + beta_dot * v_x;
+    f[0] = v_x * cs_cos(phi) - v_y * cs_sin(phi);
+    f[1] = v_x * cs_sin(phi) + v_y * cs_cos(phi);
+    f[2] = r;
+    f[3] = v_dot * cosbeta - beta_dot * v_y;
+    f[4] = v_y_dot;
+    f[5] = v_y_dot / l_R;
+    f[6] = T_dot;
+    f[7] = delta_dot;
+}
+
+/* dyn6 (python/models.py:310-452), explicit form: the same 2x2 solve for (a_x, a_y) as fdyn6.  Differences to fdyn6 as the
+ * reference writes them: slip angles atan2(v_y_w, v_x_w) - delta in the body frame (:376-379), every wheel on its own slip
+ * angle (:380-395), drag with tanh(1000 v_x) (:398), r_kin = v_x sin(beta) / l_R (:409). */
+static void dyn6_cs(const cplx *x, const cplx *u, cplx *f)
+{
+    const double rwd = l_R / wheelbase;
+    cplx phi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
+    cplx sd = cs_sin(delta), cd = cs_cos(delta);
+    cplx F_downforce = 0.5 * C_downforce * v_x * v_x;
+    const double static_weight = 0.5 * m_ * g_ * l_F / wheelbase;
+    const double cx = 0.5 * m_ * z_CG / wheelbase, cy = 0.5 * m_ * z_CG / axle_track;
+    cplx base = static_weight + 0.25 * F_downforce;
+    static const double sx[4] = {-1.0, -1.0, 1.0, 1.0};
+    static const double sy[4] = {1.0, -1.0, 1.0, -1.0};
+    cplx v_x_L = v_x - 0.5 * axle_track * r, v_x_R = v_x + 0.5 * axle_track * r;
+    cplx v_y_F = v_y + l_F * r, v_y_R = v_y - l_R * r;
+    cplx alpha[4] = {cs_atan2(v_y_F, v_x_L) - delta, cs_atan2(v_y_F, v_x_R) - delta, cs_atan2(v_y_R, v_x_L), cs_atan2(v_y_R, v_x_R)};
+    cplx glat[4], glon[4];
+    for (int k = 0; k < 4; k++) glat[k] = cs_lat_pacejka(alpha[k]);
+    cplx F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * cs_tanh(1000.0 * v_x);
+    cplx tandelta = cs_tan(delta);
+    cplx sinbeta = rwd * tandelta / cs_sqrt(1.0 + rwd * rwd * tandelta * tandelta);
+    cplx delta_tau = K_tv * (v_x * sinbeta / l_R - r);
+    cplx denom = -m_ * g_ - 0.25 * F_downforce;
+    glon[0] = C_m0 * (T - delta_tau) / denom; glon[1] = C_m0 * (T + delta_tau) / denom;
+    glon[2] = glon[0]; glon[3] = glon[1];
+    cplx cxk[4], cyk[4], czk[4];
+    cxk[0] = glon[0] * cd - glat[0] * sd;  cyk[0] = glon[0] * sd + glat[0] * cd;
+    cxk[1] = glon[1] * cd - glat[1] * sd;  cyk[1] = glon[1] * sd + glat[1] * cd;
+    cxk[2] = glon[2];                      cyk[2] = glat[2];
+    cxk[3] = glon[3];                      cyk[3] = glat[3];
+    czk[0] = -cxk[0] * (0.5 * axle_track) + cyk[0] * l_F;
+    czk[1] = cxk[1] * (0.5 * axle_track) + cyk[1] * l_F;
+    czk[2] = -glon[2] * (0.5 * axle_track) - glat[2] * l_R;
+    czk[3] = glon[3] * (0.5 * axle_track) - glat[3] * l_R;
+    cplx X0 = F_drag, Xx = 0, Xy = 0, Y0 = 0, Yx = 0, Yy = 0;
+    for (int k = 0; k < 4; k++) {
+        X0 -= cxk[k] * base;  Xx -= cxk[k] * (sx[k] * cx);  Xy -= cxk[k] * (sy[k] * cy);
+        Y0 -= cyk[k] * base;  Yx -= cyk[k] * (sx[k] * cx);  Yy -= cyk[k] * (sy[k] * cy);
+    }
+    cplx a11 = m_ - Xx, a12 = -Xy, a21 = -Yx, a22 = m_ - Yy;
+    cplx det = a11 * a22 - a12 * a21;
+    cplx a_x = (X0 * a22 - a12 * Y0) / det, a_y = (a11 * Y0 - a21 * X0) / det;
+    cplx Mz = 0;
+    for (int k = 0; k < 4; k++) Mz += czk[k] * -(base + sx[k] * cx * a_x + sy[k] * cy * a_y);
+    f[0] = v_x * cs_cos(phi) - v_y * cs_sin(phi);
+    f[1] = v_x * cs_sin(phi) + v_y * cs_cos(phi);
+    f[2] = r;
+    f[3] = a_x + v_y * r;
+    f[4] = a_y - v_x * r;
+    f[5] = Mz / I_z;
+    f[6] = (u[0] - T) / t_T;
+    f[7] = (u[1] - delta) / t_delta;
+}
+
 static void f_cs(int model, const cplx *x, const cplx *u, const double *s_ref, const double *kappa_ref, int nk, cplx *f)
 {
-    if (model == ORC_MODEL_FDYN6 || model == ORC_MODEL_FDYN6U) fdyn6_cs(x, u, s_ref, kappa_ref, nk, f, model == ORC_MODEL_FDYN6U);
+    if (model == ORC_MODEL_KIN6) kin6_cs(x, u, f);
+    else if (model == ORC_MODEL_DYN6) dyn6_cs(x, u, f);
+    else if (model == ORC_MODEL_FDYN6 || model == ORC_MODEL_FDYN6U) fdyn6_cs(x, u, s_ref, kappa_ref, nk, f, model == ORC_MODEL_FDYN6U);
     else fkin6_cs(x, u, s_ref, kappa_ref, nk, f);
 }
 

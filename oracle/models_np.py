@@ -89,6 +89,87 @@ def fkin6(x, u, s_ref, kappa_ref):
     ])
 
 
+def kin6(x, u, s_ref=None, kappa_ref=None):
+    """Cartesian kinematic model, python/models.py:168-229."""
+    X, Y, phi, v_x, v_y, r, T, delta = x
+    u_T, u_delta = u
+    delta_dot = (u_delta - delta) / t_delta
+    T_dot = (u_T - T) / t_T
+    F_motor = C_m0 * T
+    F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * smooth_sgn(v_x)
+    F_Rx = 0.5 * F_motor + F_drag
+    F_Fx = 0.5 * F_motor
+    tandelta = np.tan(delta)
+    rw = rear_weight_distribution
+    beta = np.arctan(rw * tandelta)
+    sinbeta = rw * tandelta / np.sqrt(1 + rw * rw * tandelta * tandelta)
+    cosbeta = 1 / np.sqrt(1 + rw * rw * tandelta * tandelta)
+    beta_dot = rw * (1 + tandelta * tandelta) / (1 + rw * rw * tandelta * tandelta) * delta_dot
+    v_dot = (F_Rx * cosbeta + F_Fx * np.cos(delta - beta)) / m
+    return np.array([
+        v_x * np.cos(phi) - v_y * np.sin(phi),
+        v_x * np.sin(phi) + v_y * np.cos(phi),
+        r,
+        v_dot * cosbeta - beta_dot * v_y,
+        v_dot * sinbeta + beta_dot * v_x,
+        (v_dot * sinbeta + beta_dot * v_x) / l_R,
+        T_dot,
+        delta_dot,
+    ])
+
+
+def dyn6_residual(xdot, x, u):
+    """Implicit residual of the Cartesian dynamic model in the order of python/models.py:421-452."""
+    X, Y, phi, v_x, v_y, r, T, delta = x
+    u_T, u_delta = u
+    X_dot, Y_dot, phi_dot, v_x_dot, v_y_dot, r_dot, T_dot, delta_dot = xdot
+    a_x = v_x_dot - v_y * r
+    a_y = v_y_dot + v_x * r
+    F_downforce = 0.5 * C_downforce * v_x * v_x
+    lon_wt = 0.5 * m * a_x * z_CG / wheelbase
+    lat_wt = 0.5 * m * a_y * z_CG / axle_track
+    F_z_FL = -(static_weight - lon_wt + lat_wt + 0.25 * F_downforce)
+    F_z_FR = -(static_weight - lon_wt - lat_wt + 0.25 * F_downforce)
+    F_z_RL = -(static_weight + lon_wt + lat_wt + 0.25 * F_downforce)
+    F_z_RR = -(static_weight + lon_wt - lat_wt + 0.25 * F_downforce)
+    v_x_FL = v_x - 0.5 * axle_track * r
+    v_x_FR = v_x + 0.5 * axle_track * r
+    v_x_RL, v_x_RR = v_x_FL, v_x_FR
+    v_y_FL = v_y_FR = v_y + l_F * r
+    v_y_RL = v_y_RR = v_y - l_R * r
+    alpha_FL = np.arctan2(v_y_FL, v_x_FL) - delta
+    alpha_FR = np.arctan2(v_y_FR, v_x_FR) - delta
+    alpha_RL = np.arctan2(v_y_RL, v_x_RL)
+    alpha_RR = np.arctan2(v_y_RR, v_x_RR)
+    F_y_FL, F_y_FR = F_z_FL * lat_pacejka(alpha_FL), F_z_FR * lat_pacejka(alpha_FR)
+    F_y_RL, F_y_RR = F_z_RL * lat_pacejka(alpha_RL), F_z_RR * lat_pacejka(alpha_RR)
+    F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * np.tanh(1000 * v_x)
+    tandelta = np.tan(delta)
+    rw = rear_weight_distribution
+    sinbeta = rw * tandelta / np.sqrt(1 + rw * rw * tandelta * tandelta)
+    delta_tau = K_tv * (v_x * sinbeta / l_R - r)
+    den = -m * g - 0.25 * F_downforce
+    F_x_FL = C_m0 * (T - delta_tau) * F_z_FL / den
+    F_x_FR = C_m0 * (T + delta_tau) * F_z_FR / den
+    F_x_RL = C_m0 * (T - delta_tau) * F_z_RL / den
+    F_x_RR = C_m0 * (T + delta_tau) * F_z_RR / den
+    cd, sd = np.cos(delta), np.sin(delta)
+    return np.array([
+        X_dot - (v_x * np.cos(phi) - v_y * np.sin(phi)),
+        Y_dot - (v_x * np.sin(phi) + v_y * np.cos(phi)),
+        phi_dot - r,
+        m * a_x - ((F_x_FR + F_x_FL) * cd - (F_y_FR + F_y_FL) * sd + F_x_RR + F_x_RL + F_drag),
+        m * a_y - ((F_x_FR + F_x_FL) * sd + (F_y_FR + F_y_FL) * cd + F_y_RR + F_y_RL),
+        I_z * r_dot - (
+            (F_x_FR * cd - F_y_FR * sd) * axle_track / 2 + (F_x_FR * sd + F_y_FR * cd) * l_F
+            - (F_x_FL * cd - F_y_FL * sd) * axle_track / 2 + (F_x_FL * sd + F_y_FL * cd) * l_F
+            + F_x_RR * axle_track / 2 - F_y_RR * l_R - F_x_RL * axle_track / 2 - F_y_RL * l_R
+        ),
+        T_dot - (u_T - T) / t_T,
+        delta_dot - (u_delta - delta) / t_delta,
+    ])
+
+
 def fdyn6_residual(xdot, x, u, s_ref, kappa_ref, uncrossed=False):
     """Implicit residual exactly in the order of python/models.py:574-606."""
     s, n, psi, v_x, v_y, r, T, delta = x

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libihm2_oracle.so")
 NX, NU, NZ, NY, NC, NG, NH = 8, 2, 10, 12, 14, 2, 2
-MODEL_FKIN6, MODEL_FDYN6, MODEL_FDYN6U = 0, 1, 2
+MODEL_FKIN6, MODEL_FDYN6, MODEL_FDYN6U, MODEL_KIN6, MODEL_DYN6 = 0, 1, 2, 3, 4
 INTEG_RK4 = 0
 
 _dp = C.POINTER(C.c_double)
@@ -120,6 +120,35 @@ def qp_solve(H, g, A, Bm, b, dx0, R, dl, du, iter_max=50, tol=1e-6, mu0=0.03, ta
             C.c_double(mu0), C.c_double(tau0), dz.ctypes.data_as(_dp), pi.ctypes.data_as(_dp),
             lam.ctypes.data_as(_dp), t.ctypes.data_as(_dp), sl.ctypes.data_as(_dp), stats.ctypes.data_as(_dp), C.byref(iters))
     return dict(status=st, dz=dz, pi=pi, lam=lam, t=t, sl=sl, stats=stats, iters=iters.value)
+
+
+def project(s_ref, X_ref, Y_ref, phi_ref, X, Y, s_guess, s_tol=2.0):
+    sr, sp = _d(s_ref); Xr, Xp = _d(X_ref); Yr, Yp = _d(Y_ref); pr, pp = _d(phi_ref)
+    out = [C.c_double(0.0) for _ in range(4)]
+    lib().orc_project(sp, Xp, Yp, pp, C.c_int(len(sr)), C.c_double(X), C.c_double(Y), C.c_double(s_guess), C.c_double(s_tol),
+                      *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def cart_to_frenet(s_ref, X_ref, Y_ref, phi_ref, x_cart, s_guess, s_tol=2.0, track_id=None):
+    """Tables (ntracks, nk); x_cart (B,8); s_guess (B) -> (x_frenet (B,8), next s_guess (B))."""
+    sr, sp = _d(np.atleast_2d(s_ref)); Xr, Xp = _d(np.atleast_2d(X_ref)); Yr, Yp = _d(np.atleast_2d(Y_ref)); pr, pp = _d(np.atleast_2d(phi_ref))
+    xc, xcp = _d(x_cart)
+    B = xc.shape[0]
+    sg = np.array(s_guess, dtype=np.float64).copy()
+    tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
+    xf = np.zeros((B, NX))
+    lib().orc_cart_to_frenet(C.c_int(B), C.c_int(sr.shape[0]), C.c_int(sr.shape[1]), sp, Xp, Yp, pp, tp, xcp, sg.ctypes.data_as(_dp),
+                             C.c_double(s_tol), xf.ctypes.data_as(_dp))
+    return xf, sg
+
+
+def sim_step_cart(x, u, model, M, dt=0.05, v_dyn=3.0):
+    """Cartesian plant: model MODEL_KIN6, MODEL_DYN6 or -3 (speed switch + no reversing, src/ihm2/src/sim_node.cpp:197-257)."""
+    x, xp = _d(x); u, up = _d(u)
+    xn = np.zeros_like(x)
+    lib().orc_sim_step_cart(C.c_int(x.shape[0]), C.c_int(model), C.c_int(M), C.c_double(dt), C.c_double(v_dyn), xp, up, xn.ctypes.data_as(_dp))
+    return xn
 
 
 class OracleProblem:
