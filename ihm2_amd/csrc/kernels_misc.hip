@@ -130,7 +130,8 @@ void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_fail
     hipLaunchKernelGGL(k_init_guess<MD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,      \
                        v_ref_scale, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x0, h->lbu, h->ubu, h->lg, h->ug,    \
                        h->x, h->u, mask, h->pi, h->lam)
-    if (h->cfg.model == IHM2MPC_MODEL_FDYN6U) LAUNCH_IG(IHM2MPC_MODEL_FDYN6U);
+    // recovery of a few failed instances: the kinematic rollout is 5x cheaper and its defects are what one RTI step absorbs
+    if (h->cfg.model == IHM2MPC_MODEL_FDYN6U && !only_failed) LAUNCH_IG(IHM2MPC_MODEL_FDYN6U);
     else LAUNCH_IG(IHM2MPC_MODEL_FKIN6);
 #undef LAUNCH_IG
 }
