@@ -600,9 +600,11 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                     continue;
                 }
                 if (pass == 0) {
-                    if (al) c += (lam_l[r] * t_l[r] + lam_l[r] * rd_l[r]) / t_l[r];
-                    if (au) c -= (lam_u[r] * t_u[r] + lam_u[r] * rd_u[r]) / t_u[r];
-                    SLOT_ACC(gam[s_kc[r]], (al ? lam_l[r] / t_l[r] : 0.0) + (au ? lam_u[r] / t_u[r] : 0.0));
+                    // one reciprocal per side serves the coefficient and the barrier weight
+                    const double gl = al ? lam_l[r] / t_l[r] : 0.0, gu = au ? lam_u[r] / t_u[r] : 0.0;
+                    if (al) c += fma(gl, rd_l[r], lam_l[r]);        // (lam t + lam rd) / t
+                    if (au) c -= fma(gu, rd_u[r], lam_u[r]);
+                    SLOT_ACC(gam[s_kc[r]], gl + gu);
                 } else {
                     if (al) c += (dla_l[r] * dta_l[r] - mu_t) / t_l[r];
                     if (au) c -= (dla_u[r] * dta_u[r] - mu_t) / t_u[r];
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
 /*@S:11*/
             // ---- slack / multiplier steps, step length ----
-            double amax = 1.0, amax_d = 1.0, mu_aff = 0.0;
+            double amax = 1.0, amax_d = 1.0, mu_aff = 0.0, rmax = 1.0, rmax_d = 1.0;
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
                 dlam_l[r] = dlam_u[r] = dt_l[r] = dt_u[r] = 0.0;
@@ -850,19 +852,22 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 if (fin(s_dl[r])) {
                     const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + dla_l[r] * dta_l[r] - mu_t;
                     dt_l[r] = drz + rd_l[r];
-                    dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) / t_l[r];
-                    if (dt_l[r] < 0.0) amax = fmin(amax, -t_l[r] / dt_l[r]);
-                    if (dlam_l[r] < 0.0) amax_d = fmin(amax_d, -lam_l[r] / dlam_l[r]);
+                    const double it = 1.0 / t_l[r];
+                    dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) * it;
+                    rmax = fmax(rmax, -dt_l[r] * it);                 // largest step = 1 / max(-dt / t)
+                    rmax_d = fmax(rmax_d, -dlam_l[r] / lam_l[r]);
                 }
                 if (fin(s_du[r])) {
                     const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + dla_u[r] * dta_u[r] - mu_t;
                     dt_u[r] = -drz + rd_u[r];
-                    dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) / t_u[r];
-                    if (dt_u[r] < 0.0) amax = fmin(amax, -t_u[r] / dt_u[r]);
-                    if (dlam_u[r] < 0.0) amax_d = fmin(amax_d, -lam_u[r] / dlam_u[r]);
+                    const double it = 1.0 / t_u[r];
+                    dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) * it;
+                    rmax = fmax(rmax, -dt_u[r] * it);
+                    rmax_d = fmax(rmax_d, -dlam_u[r] / lam_u[r]);
                 }
             }
-            amax = wave_min(amax); amax_d = wave_min(amax_d);
+            // hard sides collect max(-dt/t), max(-dlam/lam) (>= 1 matters only); soft sides the step bounds themselves
+            amax = wave_min(fmin(amax, 1.0 / rmax)); amax_d = wave_min(fmin(amax_d, 1.0 / rmax_d));
             if (pass == 0) {
                 if (a.m_act == 0) { alpha = alpha_d = 1.0; break; }
 #pragma unroll
