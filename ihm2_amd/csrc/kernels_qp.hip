@@ -4,27 +4,30 @@
 //
 // QP per instance (k = 0..N, z_k = (dx_k, du_k)):
 //   min  sum 1/2 z_k' H_k z_k + g_k' z_k     s.t.  dx_0 = x0 - x_0,  dx_{k+1} = A_k dx_k + B_k du_k + b_k,
-//        lb - c(z) <= R_k z_k <= ub - c(z)   (8 state boxes, 2 input boxes, 2 general rows [C D])
+//        lb - c(z) <= R_k z_k <= ub - c(z)   (8 state boxes, 2 input boxes, 2 general rows [C D], 2 track rows h;
+//                                             any side may be soft: slack s >= 0 with cost z s + 1/2 Z s^2)
 // H_k = cost_scale * V'W_kV is constant and shared by the batch (python/mpc.py:49-64); g_k = H_k z_k - Gy_k yref_k.
-// Solver: Mehrotra predictor-corrector primal-dual interior point; the Newton system is reduced to
-// an equality-constrained LQ problem solved by a Riccati recursion.  Tolerances are relative to
-// sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
+// Solver: Mehrotra predictor-corrector primal-dual interior point with separate primal / dual step lengths; the Newton
+// system is reduced to an equality-constrained LQ problem solved by a Riccati recursion (soft sides: their slack block is
+// eliminated per constraint first).  Tolerances are relative to sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
 //
-// Mapping: ONE WAVEFRONT PER INSTANCE (block = 64 lanes), 4 instances per CU (38.5 KB of LDS each).
-//   * LDS: iterate z, pi, modified gradient, dynamics residual, Riccati vectors p_k, gains K_k, step dz.
-//   * registers: multipliers / slacks / their steps -- each lane owns NSLOT two-sided constraint slots
-//     (320 slots at the reference's dimensions = 5 per lane).
-//   * HBM/L2: linearisation records [A|B|b] (704 B per stage) are STREAMED through a two-slot LDS
-//     staging buffer by a register ring that runs four stages ahead of each sequential sweep (one
-//     coalesced wave load per record); P_k (512 B) is stored once per factorisation, read back in a
-//     fully parallel phase.
-//   * the three sequential recursions are one LDS hop per stage each:
-//       factor   P_k = Gxx - Gux' Guu^-1 Gux          (three hops: W = P[A B], G = H~ + [A B]'W, P/K)
-//       vector   p_k = gt_x - K'gt_u + (A - B K)'(P_{k+1} rb_k + p_{k+1})
-//       forward  dx_{k+1} = rb_k - B kff_k + (A - B K) dx_k
-//     with kff_k, du_k and dpi_k recovered afterwards in parallel over all stages.
-//   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands from LDS (row reads broadcast,
-//     column reads consecutive: conflict-free); wave reductions by cross-lane shuffles.
+// Mapping: ONE WAVEFRONT PER INSTANCE (block = 64 lanes), 4 instances per CU (38.5 - 40.6 KB of LDS each).
+//   * LDS: iterate z, pi, modified gradient, dynamics residual, Riccati vectors p_k, gains K_k, step dz; with UNI the
+//     batch-shared stage Hessian and general rows.
+//   * registers: multipliers / slacks / their steps -- each lane owns NSLOT constraint slots (320 two-sided slots at the
+//     reference's dimensions = 5 per lane; soft sides are one-sided slots with 8 more registers each).
+//   * HBM/L2: linearisation records [A|B|b] (704 B per stage) are STREAMED through LDS staging slots by a register ring
+//     that runs four stages ahead of each sweep (one coalesced wave load per record); P_k and M_k = A - B K_k (512 B each)
+//     are stored once per factorisation; M_k is streamed back by the vector recursion (transposed lane map) and the
+//     forward recursion, P_k is read back in a fully parallel phase.
+//   * the three sequential recursions:
+//       factor   P_k = Gxx - Gux' Guu^-1 Gux          (three LDS hand-offs: W = P[A B], G = H~ + [A B]'W, P/K/M)
+//       vector   p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1})      } carried in REGISTERS: the 8-term contractions
+//       forward  dx_{k+1} = rb_k - B kff_k + M_k dx_k                     } alternate between DPP (inside a group of 8
+//     lanes) and DPP + v_permlane16/32_swap (across the groups), so a stage's result is laid out as the next one's operand;
+//     kff_k, du_k and dpi_k are recovered afterwards in parallel over all stages.
+//   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands from LDS (row reads broadcast, column reads
+//     consecutive: conflict-free); wave reductions by DPP / permlane butterflies (VALU speed, no LDS crossbar).
 #include "ihm2mpc_internal.h"
 
 namespace {

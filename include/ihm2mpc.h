@@ -21,12 +21,18 @@
  *   ihm2mpc_get_status        <- return value of solve()                        python/main.py:325-328; dpc/main.py:287-293
  *   ihm2mpc_get_residuals     <- solver.get_stats("residuals") (acados)
  *   ihm2mpc_sim_step          <- AcadosSimSolver.simulate(x,u)                  python/main.py:476-502; python/sim.py:9-25
+ *   ihm2mpc_step              <- one iteration of the MiL loop (plant + compute_control)  python/main.py:476-517
+ *   ihm2mpc_set_soft          <- ocp.constraints.idxsbx/idxsg/idxsh, cost.zl..Zu         old/generate_acaods_interface.py:380-449
+ *   ihm2mpc_set_path_constraints <- model.con_h_expr (track rows), constraints.lh/uh     old/generate_acaods_interface.py:191-212,411-449
+ *   ihm2mpc_set_track_geometry, ihm2mpc_project <- Track(csv), Track::project + Frenet states
+ *                                                   src/ihm2/src/common/tracks.cpp:132-288; mpc_control_node.cpp:142-157
+ *   ihm2mpc_sim_step_cart     <- ihm2_kin6/dyn6_acados_sim_solve + switch + clamp        src/ihm2/src/sim_node.cpp:197-257
  *
  * Conventions
  *   x = (s, n, psi, v_x, v_y, r, T, delta), u = (u_T, u_delta)   (python/models.py:236-245)
  *   All host arrays are C-contiguous, instance-major: x (B,N+1,8), u (B,N,2), yref (B,N,12) ...
  *   Every setter copies in, every getter copies out; no caller pointer is kept after return.
- *   A handle owns its device memory and one HIP stream; it is not thread-safe; distinct handles
+ *   A handle owns its device memory and its HIP streams (one, plus a helper stream inside ihm2mpc_step); it is not thread-safe; distinct handles
  *   are independent (one per device for multi-GPU sharding).
  *   Return value: 0 = ok, < 0 = API misuse or HIP error (text in ihm2mpc_last_error()).
  *   Per-instance solver status (acados codes): 0 success, 1 NaN/failure, 2 max iterations (SQP
