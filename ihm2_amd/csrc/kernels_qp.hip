@@ -855,22 +855,35 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 if (fin(s_dl[r])) {
                     const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + dla_l[r] * dta_l[r] - mu_t;
                     dt_l[r] = drz + rd_l[r];
-                    const double it = 1.0 / t_l[r];
-                    dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) * it;
-                    rmax = fmax(rmax, -dt_l[r] * it);                 // largest step = 1 / max(-dt / t)
-                    rmax_d = fmax(rmax_d, -dlam_l[r] / lam_l[r]);
+                    if (NSOFT == 0) {       // all-hard tables: one reciprocal per side, step bound as 1 / max(-dt / t)
+                        const double it = 1.0 / t_l[r];
+                        dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) * it;
+                        rmax = fmax(rmax, -dt_l[r] * it);
+                        rmax_d = fmax(rmax_d, -dlam_l[r] / lam_l[r]);
+                    } else {                // (the soft instantiations are register-bound: two more live values cost more than they save)
+                        dlam_l[r] = -(rm + lam_l[r] * dt_l[r]) / t_l[r];
+                        if (dt_l[r] < 0.0) amax = fmin(amax, -t_l[r] / dt_l[r]);
+                        if (dlam_l[r] < 0.0) amax_d = fmin(amax_d, -lam_l[r] / dlam_l[r]);
+                    }
                 }
                 if (fin(s_du[r])) {
                     const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + dla_u[r] * dta_u[r] - mu_t;
                     dt_u[r] = -drz + rd_u[r];
-                    const double it = 1.0 / t_u[r];
-                    dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) * it;
-                    rmax = fmax(rmax, -dt_u[r] * it);
-                    rmax_d = fmax(rmax_d, -dlam_u[r] / lam_u[r]);
+                    if (NSOFT == 0) {
+                        const double it = 1.0 / t_u[r];
+                        dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) * it;
+                        rmax = fmax(rmax, -dt_u[r] * it);
+                        rmax_d = fmax(rmax_d, -dlam_u[r] / lam_u[r]);
+                    } else {
+                        dlam_u[r] = -(rm + lam_u[r] * dt_u[r]) / t_u[r];
+                        if (dt_u[r] < 0.0) amax = fmin(amax, -t_u[r] / dt_u[r]);
+                        if (dlam_u[r] < 0.0) amax_d = fmin(amax_d, -lam_u[r] / dlam_u[r]);
+                    }
                 }
             }
             // hard sides collect max(-dt/t), max(-dlam/lam) (>= 1 matters only); soft sides the step bounds themselves
-            amax = wave_min(fmin(amax, 1.0 / rmax)); amax_d = wave_min(fmin(amax_d, 1.0 / rmax_d));
+            if (NSOFT == 0) { amax = fmin(amax, 1.0 / rmax); amax_d = fmin(amax_d, 1.0 / rmax_d); }
+            amax = wave_min(amax); amax_d = wave_min(amax_d);
             if (pass == 0) {
                 if (a.m_act == 0) { alpha = alpha_d = 1.0; break; }
 #pragma unroll
