@@ -475,3 +475,36 @@ def test_other_horizons_match_oracle(track, Nh, B):
         assert np.max(np.abs(pg[ok] - pi[ok])) / (1.0 + np.abs(pi).max()) < 1e-6
         s.set_x(x); s.set_u(u); s.set_multipliers(pi, lam)
     s.free()
+
+
+def test_misuse_of_the_extended_abi_is_reported(track):
+    from ihm2_amd import _lib
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = 4
+    s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+    z = np.zeros((N + 1, 28)); Z = np.full((N + 1, 28), -1.0)
+    Z[3, 1] = 0.0                                            # soft without any penalty
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.set_soft(z, Z)
+    Z[3, 1] = 1.0; z[3, 1] = -1.0                             # decreasing linear penalty
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.set_soft(z, Z)
+    with pytest.raises(_lib.Ihm2mpcError):                   # too many soft sides for the kernel's slack registers
+        s.set_soft(np.ones((N + 1, 28)), np.ones((N + 1, 28)))
+    s.set_soft(None, None)
+    lh, uh, w = np.array([0.0, 0.0]), np.array([-1.0, 0.0]), np.array([[1.5, 1.5]])
+    c_dp = _lib.c_double_p
+    with pytest.raises(_lib.Ihm2mpcError):                   # lh > uh
+        _lib.check(s.lib.ihm2mpc_set_path_constraints(s._h, 1, 3.19, 1.55, w.ctypes.data_as(c_dp), lh.ctypes.data_as(c_dp), uh.ctypes.data_as(c_dp)))
+    with pytest.raises(_lib.Ihm2mpcError):                   # projection before the geometry is known
+        s.project(np.zeros((B, 8)), np.zeros(B))
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.sim_step_cart(np.zeros((B, 8)), np.zeros((B, 2)), model=7)
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.step(40.0, model=9, M_sim=10)
+    # the handle is still usable
+    s.set_x0(sample_x0(track, B, seed=3)); s.init_guess()
+    s.step(40.0, model=0, M_sim=25)
+    assert np.all(s.get_status() == 0)
+    s.free()

@@ -56,3 +56,87 @@ def test_unsupported_options_are_rejected():
         ocp.flatten()
     with pytest.raises(ValueError):
         O.get_acados_model_from_explicit_dynamics("x", "kin4", 8, 2, 10)
+
+
+def test_soft_sides_and_track_rows_flatten_to_the_abi_layout():
+    """acados names (old/generate_acaods_interface.py:380-449) -> (N+1, 28) arrays: 14 lower sides then 14 upper sides."""
+    N = 10
+    ocp = make_ocp(N=N)
+    ocp.model.con_h_expr = "track"
+    c = ocp.constraints
+    c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.zeros(2)
+    c.idxsbx = np.array([1])                      # position in idxbx = [1,3,6,7]: v_x
+    c.idxsg = np.array([0])                       # torque-rate row
+    c.idxsh = np.array([0, 1]); c.idxsh_e = np.array([1])
+    c.idxsbx_e = np.array([0])                    # position in idxbx_e = [1,3,4,5]: n
+    ocp.cost.zl = np.array([1.0, 2.0, 3.0, 4.0]); ocp.cost.zu = ocp.cost.zl + 10
+    ocp.cost.Zl = ocp.cost.zl + 20; ocp.cost.Zu = ocp.cost.zl + 30
+    ocp.cost.zl_e = np.array([5.0, 6.0]); ocp.cost.zu_e = ocp.cost.zl_e + 10
+    ocp.cost.Zl_e = ocp.cost.zl_e + 20; ocp.cost.Zu_e = ocp.cost.zl_e + 30
+    d = ocp.flatten()
+    assert d.path_on == 1 and d.soft_z.shape == (N + 1, 28) and d.soft_Z.shape == (N + 1, 28)
+    np.testing.assert_array_equal(d.lh, [-1e3, -1e3]); np.testing.assert_array_equal(d.uh, [0, 0])
+    soft = d.soft_Z >= 0
+    # stage rows: v_x box (row 3) at k = 1..N-1; rate row 10 at k = 0..N-1; track rows 12, 13 at k = 1..N-1
+    assert soft[1:N, 3].all() and soft[1:N, 14 + 3].all() and not soft[0, 3] and not soft[N, 3]
+    assert soft[:N, 10].all() and soft[:N, 24].all() and not soft[N, 10]
+    assert soft[1:N, 12].all() and soft[1:N, 13].all() and soft[1:N, 26].all() and soft[1:N, 27].all() and not soft[0, 12]
+    # terminal: n box (row 1) and the left track row (13)
+    assert soft[N, 1] and soft[N, 15] and soft[N, 13] and soft[N, 27] and not soft[N, 12]
+    assert soft.sum() == 2 * ((N - 1) + N + 2 * (N - 1) + 2)
+    # the penalties land on their sides: lower = zl / Zl, upper = zu / Zu, order [sbx, sg, sh] and [sbx_e, sh_e]
+    assert (d.soft_z[1, 3], d.soft_z[1, 17], d.soft_Z[1, 3], d.soft_Z[1, 17]) == (1.0, 11.0, 21.0, 31.0)
+    assert (d.soft_z[0, 10], d.soft_Z[0, 24]) == (2.0, 32.0)
+    assert (d.soft_z[2, 12], d.soft_z[2, 13], d.soft_Z[2, 27]) == (3.0, 4.0, 34.0)
+    assert (d.soft_z[N, 1], d.soft_Z[N, 15], d.soft_z[N, 13], d.soft_Z[N, 27]) == (5.0, 35.0, 6.0, 36.0)
+    desc = d.as_dict(np.linspace(0, 1, 4), np.zeros(4), track_widths=[[1.5, 1.6]])
+    assert desc["path_on"] == 1 and desc["widths"].shape == (1, 2) and desc["car_L"] == pytest.approx(3.19)
+
+
+def test_soft_and_track_row_misuse_is_rejected():
+    ocp = make_ocp()
+    ocp.constraints.idxsbx = np.array([0])                 # penalties missing
+    with pytest.raises(ValueError):
+        ocp.flatten()
+    ocp = make_ocp()
+    ocp.constraints.lh = np.array([-1e3, -1e3])            # rows given without the model expression
+    with pytest.raises(ValueError):
+        ocp.flatten()
+    ocp = make_ocp()
+    ocp.model.con_h_expr = "track"
+    ocp.constraints.lh = ocp.constraints.lh_e = np.array([-1e3, -1e3])
+    ocp.constraints.uh = np.zeros(2); ocp.constraints.uh_e = np.ones(2)      # terminal rows must equal the stage rows
+    with pytest.raises(ValueError):
+        ocp.flatten()
+    ocp = make_ocp()
+    ocp.model.con_h_expr = "track"
+    ocp.constraints.lh = ocp.constraints.lh_e = np.array([-1e3, -1e3]); ocp.constraints.uh = ocp.constraints.uh_e = np.zeros(2)
+    with pytest.raises(ValueError):
+        ocp.flatten().as_dict(np.linspace(0, 1, 4), np.zeros(4))            # widths missing
+
+
+def test_controller_options_build_the_expected_ocp(monkeypatch):
+    """IHM2Controller's extensions (terminal_bounds, soft_state_bounds, track rows) without touching the GPU library."""
+    from ihm2_amd import controller as Cm
+
+    captured = {}
+
+    class FakeSolver:
+        def __init__(self, ocp, B, s_ref, kappa_ref, **kw):
+            captured["ocp"], captured["kw"] = ocp, kw
+        def set_x(self, x): pass
+        def set_u(self, u): pass
+
+    monkeypatch.setattr(Cm, "BatchedOcpSolver", FakeSolver)
+    s_ref = np.linspace(-10, 50, 30)
+    Cm.IHM2Controller(s_ref, np.zeros(30), batch_size=3, terminal_bounds="stage", soft_state_bounds=(7.0, 9.0), track_widths=[[1.4, 1.5]])
+    ocp = captured["ocp"]
+    assert list(ocp.constraints.idxbx_e) == [1, 3, 6, 7]                    # stage box repeated at the terminal stage
+    assert list(ocp.constraints.idxsbx) == [0, 1]                           # n and v_x soft
+    assert list(ocp.constraints.idxsbx_e) == [0, 1, 2, 3] and list(ocp.constraints.idxsh) == [0, 1]
+    np.testing.assert_array_equal(ocp.cost.zl, [7.0, 7.0, 100.0, 100.0]); np.testing.assert_array_equal(ocp.cost.Zu, [9.0, 9.0, 100.0, 100.0])
+    assert ocp.model.con_h_expr == "track" and captured["kw"]["track_widths"] == [[1.4, 1.5]]
+    d = ocp.flatten()
+    assert d.path_on == 1 and (d.soft_Z[1:40, [1, 3, 12, 13]] >= 0).all() and (d.soft_Z[1:40, [6, 7, 8, 9, 10, 11]] < 0).all()
+    with pytest.raises(ValueError):
+        Cm.IHM2Controller(s_ref, np.zeros(30), terminal_bounds="nope")
