@@ -211,6 +211,51 @@ def run_closed_loop(controller: IHM2Controller, simulator: Simulator, x0: np.nda
     return ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
 
 
+def run_closed_loop_device(controller: IHM2Controller, simulator: Simulator, x0: np.ndarray, n_steps: int, lap_length: float | None = None
+                           ) -> ClosedLoopResult:
+    """Same loop as :func:`run_closed_loop`, with the state resident on the device: one ``ihm2mpc_step`` per control period
+    (plant beside the linearisation), and per step only ``x0`` (B,8), ``u0`` (B,2) and the status (B,) cross the boundary for
+    the bookkeeping.  Frozen instances (failed / finished) are masked out of the plant (``ihm2mpc_set_active``)."""
+    B, s = controller.B, controller.solver
+    code = _PLANT_CODE[simulator.variant]
+    x = np.asarray(x0, dtype=np.float64).reshape(B, 8).copy()
+    xs, us, sts, runtimes, alive_hist = [x.copy()], [], [], [], []
+    alive = np.ones(B, dtype=bool); finished = np.zeros(B, dtype=bool); lap_time = np.full(B, np.nan)
+    t0 = time.perf_counter()
+    s.set_active(None)
+    s.set_x0(x); s.prepare_step(controller.s_target); st = s.solve(); u = s.get_u0()          # control for the initial state
+    runtimes.append((time.perf_counter() - t0) * 1e3)
+    mask_dirty = False
+    for i in range(n_steps):
+        alive_hist.append(alive.copy())
+        bad = alive & ~np.isin(st, (0, 2))
+        if bad.any():
+            alive &= ~bad; mask_dirty = True
+        us.append(np.where(alive[:, None], np.nan_to_num(u), 0.0)); sts.append(st.copy())
+        if not alive.any():
+            xs.append(x.copy())
+            break
+        if mask_dirty:
+            s.set_active(alive.astype(np.int32)); mask_dirty = False
+        t0 = time.perf_counter()
+        s.step(controller.s_target, model=code, M_sim=simulator.config.num_steps)     # x <- plant(x, u); u <- NMPC(x)
+        xn = s.get_x0(); u = s.get_u0(); st = s.get_status()
+        runtimes.append((time.perf_counter() - t0) * 1e3)
+        nan = alive & np.any(np.isnan(xn), axis=1)
+        if nan.any():
+            alive &= ~nan; mask_dirty = True
+        x = np.where(alive[:, None], xn, x)
+        if lap_length is not None:
+            done = alive & (x[:, 0] > lap_length + 1.0)
+            if done.any():
+                lap_time[done] = (i + 1) * controller.dt
+                finished |= done; alive &= ~done; mask_dirty = True
+        xs.append(x.copy())
+    controller.last_status = st
+    s.set_active(None)
+    return ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
+
+
 def closed_loop(track_data: str | MotionPlan, simulator_type=SimModelVariant.KIN6_DYN6, motion_planner_type: type | None = None,
                 motion_tracker_type: type = IHM2Controller, low_level_controller_type: type | None = None,
                 interation_end_callback: Callable | None = None, cleanup_callback: Callable | None = None, *,

@@ -154,7 +154,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     for (size_t i = 0; i < NS * NC; i++) { h->host_lb[i] = -INFINITY; h->host_ub[i] = INFINITY; }
     for (size_t i = 0; i < NS * NLAM; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
-    DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(u0, B * 2);
+    DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(active, B); DA(u0, B * 2);
     DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, B * N * 64); DA(scratch, B * 24);
 #undef DA
     *out = h;
@@ -168,7 +168,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
-                    h->status, h->qp_iter, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch};
+                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -617,7 +617,7 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
     if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
-    ihm2_launch_sim(h, model, M_sim, xs, us, xn, h->stream);
+    ihm2_launch_sim(h, model, M_sim, xs, us, xn, h->stream, nullptr);
     HIP_TRY(hipGetLastError());
     return download(h, xn, x_next, NX);
 }
@@ -628,8 +628,19 @@ int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim)
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (M_sim < 1) return fail("M_sim must be >= 1");
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
-    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream);
+    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream, h->active_set ? h->active : nullptr);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active)
+{
+    CHECK_H(h);
+    h->active_set = active != nullptr;
+    if (active) {
+        HIP_TRY(hipMemcpyAsync(h->active, active, (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 
@@ -644,7 +655,7 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream2);
+    ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream2, h->active_set ? h->active : nullptr);
     ihm2_launch_prepare(h, s_target, 1, h->stream2);
     HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
     ihm2_launch_prepare(h, s_target, 2, h->stream);

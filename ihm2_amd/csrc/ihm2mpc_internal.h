@@ -74,6 +74,8 @@ struct ihm2mpc_handle {
     double *slk;    // (B,NS,28) slack values of the soft sides after the last QP (0 for hard sides)
     double *res;    // (B,4)
     int32_t *status, *qp_iter;   // (B)
+    int32_t *active;             // (B) plant mask of the device-resident closed loop (nullptr-equivalent while !active_set)
+    bool active_set;
     double *u0;     // (B,2) first control of the last solve
 
     double *lin;    // (B,N,88) linearisation records [A | B | b]
@@ -90,7 +92,8 @@ void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits
-void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream);
+void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,
+                     const int32_t *active);
 void ihm2_launch_sim_cart(ihm2mpc_handle *h, int model, int M, double dt, int n_steps, double v_dyn, const double *x, const double *u,
                           double *xn, hipStream_t stream);
 void ihm2_launch_project(ihm2mpc_handle *h, double s_tol, const double *xc, double *s_guess, double *xf, hipStream_t stream);

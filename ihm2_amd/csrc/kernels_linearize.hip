@@ -126,10 +126,14 @@ __global__ __launch_bounds__(64) void k_linearize(
 __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double dt, int nknots,
                                                  const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                                  const int32_t *__restrict__ track_id, const double *xs,
-                                                 const double *__restrict__ us, double *xn)
+                                                 const double *__restrict__ us, double *xn, const int32_t *__restrict__ active)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
+    if (active && !active[b]) {          // a frozen instance keeps its state (closed loops: failed or finished cars)
+        if (xn != xs) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
+        return;
+    }
     double x[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) x[i] = xs[(size_t)b * 8 + i];
@@ -186,9 +190,9 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
 }
 
-void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream)
+void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)
 {
     const int blocks = (h->B + 63) / 64;
     hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
-                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn);
+                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active);
 }

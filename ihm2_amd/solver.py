@@ -303,6 +303,16 @@ class BatchedOcpSolver:
         """x0 <- plant(x0, u0 of the last solve), on device."""
         _lib.check(self.lib.ihm2mpc_sim_advance(self._h, int(model), int(M_sim)))
 
+    def set_active(self, active=None):
+        """Plant mask for ``sim_advance`` / ``step``: instances with ``active[b] == 0`` keep their ``x0``; ``None`` = all."""
+        if active is None:
+            _lib.check(self.lib.ihm2mpc_set_active(self._h, None))
+        else:
+            a = np.ascontiguousarray(active, dtype=np.int32)
+            if a.shape != (self.B,):
+                raise ValueError(f"active must have shape ({self.B},)")
+            _lib.check(self.lib.ihm2mpc_set_active(self._h, a.ctypes.data_as(_lib.c_int32_p)))
+
     def step(self, s_target: float, model: int = 0, M_sim: int = 100):
         """One MiL iteration on the device: ``sim_advance`` + ``prepare_step`` + one RTI iteration, with the plant step
         overlapped with the linearisation.  Asynchronous; read results with ``get_u0`` / ``get_status``."""

@@ -178,6 +178,9 @@ int ihm2mpc_get_x0(ihm2mpc_handle *h, double *x0);
  * one RTI iteration.  Same results as the three calls; the plant step and the reference ramp run beside the warm-start
  * shift and the linearisation (they only meet in the QP), which hides the plant's latency. */
 int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target);
+/* plant mask (B) for sim_advance / step: an instance with active[b] == 0 keeps its x0 (a car that failed or finished its lap is
+ * frozen, as the reference's loop stops, python/main.py:503-517); NULL = all active */
+int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active);
 
 /* ---- Cartesian side of the ROS stack ----
  * Plants of the simulation node (src/ihm2/src/sim_node.cpp:197-257), state (X, Y, phi, v_x, v_y, r, T, delta): */

@@ -72,3 +72,27 @@ def test_reference_cold_start_from_rest(track):
     assert np.all(np.isfinite(res.x))
     assert np.all(res.x[-1, :, 0] > res.x[0, :, 0] + 1.0)        # the cars moved forward
     assert np.all(np.abs(res.u[..., 0]) <= 500.0 + 1e-6) and np.all(np.abs(res.u[..., 1]) <= 0.5 + 1e-9)
+
+
+def test_device_resident_loop_equals_the_host_loop(track):
+    """run_closed_loop_device (ihm2mpc_step, plant mask on device) reproduces run_closed_loop step for step."""
+    from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop, run_closed_loop_device
+    from ihm2_amd.controller import IHM2Controller
+
+    B, steps = 40, 30
+    x0 = sample_x0(track, B, seed=17)
+    out = []
+    for runner in (run_closed_loop, run_closed_loop_device):
+        ctrl = IHM2Controller(track.s_ref, track.kappa_ref, batch_size=B)
+        sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=40), SimModelVariant.KIN6_DYN6)
+        ctrl.warm_start(x0)
+        out.append(runner(ctrl, sim, x0, steps, lap_length=track.lap_length))
+        ctrl.solver.free()
+    h, d = out
+    n = min(h.u.shape[0], d.u.shape[0])
+    assert n >= 10
+    np.testing.assert_array_equal(h.alive_history[:n], d.alive_history[:n])
+    live = h.alive_history[:n]
+    np.testing.assert_allclose(d.x[:n][live], h.x[:n][live], rtol=0, atol=1e-9)        # same kernels, same order: agreement to rounding
+    np.testing.assert_allclose(d.u[:n][live], h.u[:n][live], rtol=0, atol=1e-7)
+    assert (~h.alive).any() and h.alive.any()              # the batch contains frozen and running cars: the mask is exercised
