@@ -18,16 +18,29 @@ using namespace ihm2;
 
 namespace {
 
+// position of entry (column c, row i) among the structurally non-zero sensitivities (column-major, 52 / 55 entries)
+__host__ __device__ constexpr int s_pos(int mdl, int c, int i)
+{
+    int p = 0;
+    for (int cc = 0; cc < c; cc++)
+        for (int b = 0; b < 8; b++) p += (S_COL_MASK[mdl][cc] >> b) & 1u;
+    for (int b = 0; b < i; b++) p += (S_COL_MASK[mdl][c] >> b) & 1u;
+    return p;
+}
+__host__ __device__ constexpr int s_count(int mdl) { return s_pos(mdl, 10, 0); }
+
 // one RK4 stage of sensitivity column COL:  dX = S + ah*dK_prev ; dK = Jx dX + Ju[:,COL] ; Sacc += wh*dK
+// SL != nullptr: the sub-step's base sensitivities S live in LDS (entry-major, one word per lane: Sl[pos * 64]) instead of
+// registers -- the dynamic model's forward-AD evaluation needs the registers (it spilled 868 B per lane to scratch)
 template <int MODEL, int COL>
-__device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const double (&S)[8], double (&Sacc)[8],
+__device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const double (&S)[8], const double *Sl, double (&Sacc)[8],
                                                double (&dK)[8], double ah, double wh)
 {
     constexpr unsigned cm = S_COL_MASK[MODEL ? 1 : 0][COL];
     double dX[8];
 #pragma unroll
     for (int l = 0; l < 8; l++)
-        if ((cm >> l) & 1u) dX[l] = fma(ah, dK[l], S[l]);
+        if ((cm >> l) & 1u) dX[l] = fma(ah, dK[l], Sl ? Sl[s_pos(MODEL ? 1 : 0, COL, l) * 64] : S[l]);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (!((cm >> i) & 1u)) continue;
@@ -76,11 +89,20 @@ __global__ __launch_bounds__(64) void k_linearize(
     trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
 
     // S, Sacc, dK: [column][row]; only rows in S_COL_MASK[column] are ever touched
+    constexpr bool S_IN_LDS = MODEL != IHM2MPC_MODEL_FKIN6;
+    extern __shared__ double s_lds[];
+    double *Sl = S_IN_LDS ? s_lds + threadIdx.x : nullptr;
     double S[10][8], Sacc[10][8], dK[10][8];
 #pragma unroll
     for (int c = 0; c < 10; c++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) { S[c][i] = (c == i) ? 1.0 : 0.0; dK[c][i] = 0.0; }
+        for (int i = 0; i < 8; i++) {
+            S[c][i] = (c == i) ? 1.0 : 0.0; dK[c][i] = 0.0;
+            if (S_IN_LDS) {
+                Sacc[c][i] = S[c][i];
+                if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = S[c][i];
+            }
+        }
 
     const double h = dt / M;
     for (int m = 0; m < M; m++) {
@@ -88,7 +110,7 @@ __global__ __launch_bounds__(64) void k_linearize(
 #pragma unroll
         for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
 #define COPY_S_TO_ACC(c) sens_col_copy<MODEL, c>(S[c], Sacc[c]);
-        FOR_ALL_COLS(COPY_S_TO_ACC)
+        if (!S_IN_LDS) { FOR_ALL_COLS(COPY_S_TO_ACC) }      // with S in LDS, Sacc already holds S from the previous sub-step
 #pragma unroll 1
         for (int st = 0; st < 4; st++) {
             const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
@@ -100,13 +122,20 @@ __global__ __launch_bounds__(64) void k_linearize(
             else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, K, J);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
-#define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sacc[c], dK[c], ah, wh);
+#define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sl, Sacc[c], dK[c], ah, wh);
             FOR_ALL_COLS(STAGE_COL)
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) x[i] = xacc[i];
 #define COPY_ACC_TO_S(c) sens_col_copy<MODEL, c>(Sacc[c], S[c]);
-        FOR_ALL_COLS(COPY_ACC_TO_S)
+        if (!S_IN_LDS) { FOR_ALL_COLS(COPY_ACC_TO_S) }
+        else {
+#pragma unroll
+            for (int c = 0; c < 10; c++)
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = Sacc[c][i];
+        }
     }
 
     // output record [A (8x8 row-major) | B (8x2) | b = Phi(x_k,u_k) - x_{k+1}]
@@ -114,9 +143,9 @@ __global__ __launch_bounds__(64) void k_linearize(
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL ? 1 : 0][j] >> i) & 1u) ? S[j][i] : 0.0;
+        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL ? 1 : 0][j] >> i) & 1u) ? (S_IN_LDS ? Sacc[j][i] : S[j][i]) : 0.0;
 #pragma unroll
-        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL ? 1 : 0][8 + j] >> i) & 1u) ? S[8 + j][i] : 0.0;
+        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL ? 1 : 0][8 + j] >> i) & 1u) ? (S_IN_LDS ? Sacc[8 + j][i] : S[8 + j][i]) : 0.0;
         rec[80 + i] = x[i] - xk[8 + i];
     }
 }
@@ -180,10 +209,10 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
     const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U)
-        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
-        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else
         hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FKIN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
