@@ -246,7 +246,7 @@ def main():
             "qp_iter_percentiles": {"p50": float(np.percentile(qp_iters, 50)), "p90": float(np.percentile(qp_iters, 90)),
                                     "p99": float(np.percentile(qp_iters, 99)), "max": int(np.max(qp_iters))},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(ocp, track, x0, args.cpu_budget)
         print(json.dumps(out))
     if dist is not None:
