@@ -74,6 +74,9 @@ SYMBOLS = {
     "ihm2mpc_sim_advance": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "ihm2mpc_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double]),
     "ihm2mpc_set_active": (C.c_int, [_H, c_int32_p]),
+    "ihm2mpc_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "ihm2mpc_host_free": (C.c_int, [C.c_void_p]),
+    "ihm2mpc_get_u0_async": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_track_geometry": (C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
     "ihm2mpc_sim_step_cart": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_double, c_double_p, c_double_p, c_double_p]),
     "ihm2mpc_project": (C.c_int, [_H, c_double_p, c_double_p, C.c_double, c_double_p]),

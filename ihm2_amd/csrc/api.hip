@@ -633,6 +633,27 @@ int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim)
     return 0;
 }
 
+int ihm2mpc_host_alloc(uint64_t nbytes, void **p)
+{
+    if (!p || nbytes == 0) return fail("null argument");
+    HIP_TRY(hipHostMalloc(p, nbytes, hipHostMallocDefault));
+    return 0;
+}
+
+int ihm2mpc_host_free(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return 0;
+}
+
+int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst)
+{
+    CHECK_H(h);
+    if (!pinned_dst) return fail("null argument");
+    HIP_TRY(hipMemcpyAsync(pinned_dst, h->u0, (size_t)h->B * NU * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
 int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active)
 {
     CHECK_H(h);

@@ -68,6 +68,10 @@ class BatchedOcpSolver:
     # ---- lifetime ----
     def free(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ihm2mpc_synchronize(self._h)
+            for ptr in getattr(self, "_pinned", []):
+                self.lib.ihm2mpc_host_free(ptr)
+            self._pinned = []
             self.lib.ihm2mpc_free(self._h)
             self._h = C.c_void_p()
 
@@ -302,6 +306,20 @@ class BatchedOcpSolver:
     def sim_advance(self, model: int = 0, M_sim: int = 100):
         """x0 <- plant(x0, u0 of the last solve), on device."""
         _lib.check(self.lib.ihm2mpc_sim_advance(self._h, int(model), int(M_sim)))
+
+    def alloc_pinned(self, shape):
+        """float64 array in pinned host memory (for :meth:`get_u0_async`); freed with the solver."""
+        n = int(np.prod(shape))
+        ptr = C.c_void_p()
+        _lib.check(self.lib.ihm2mpc_host_alloc(C.c_uint64(n * 8), C.byref(ptr)))
+        self._pinned = getattr(self, "_pinned", []) + [ptr]
+        return np.ctypeslib.as_array(C.cast(ptr, _lib.c_double_p), shape=(n,)).reshape(shape)
+
+    def get_u0_async(self, out):
+        """Enqueue the copy of ``u0`` (B,2) into the pinned array ``out``; valid after :meth:`synchronize`."""
+        if out.shape != (self.B, NU) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 (B, 2) array from alloc_pinned")
+        _lib.check(self.lib.ihm2mpc_get_u0_async(self._h, _ptr(out)))
 
     def set_active(self, active=None):
         """Plant mask for ``sim_advance`` / ``step``: instances with ``active[b] == 0`` keep their ``x0``; ``None`` = all."""

@@ -181,6 +181,11 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
 /* plant mask (B) for sim_advance / step: an instance with active[b] == 0 keeps its x0 (a car that failed or finished its lap is
  * frozen, as the reference's loop stops, python/main.py:503-517); NULL = all active */
 int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active);
+/* pipelined read-back: u0 (B,2) of the last solve is copied to PINNED host memory (ihm2mpc_host_alloc) in stream order, without
+ * waiting -- the next ihm2mpc_step can be enqueued at once; the data is valid after ihm2mpc_synchronize (or any blocking getter) */
+int ihm2mpc_host_alloc(uint64_t nbytes, void **p);
+int ihm2mpc_host_free(void *p);
+int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
 
 /* ---- Cartesian side of the ROS stack ----
  * Plants of the simulation node (src/ihm2/src/sim_node.cpp:197-257), state (X, Y, phi, v_x, v_y, r, T, delta): */

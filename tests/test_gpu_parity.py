@@ -508,3 +508,30 @@ def test_misuse_of_the_extended_abi_is_reported(track):
     s.step(40.0, model=0, M_sim=25)
     assert np.all(s.get_status() == 0)
     s.free()
+
+
+def test_pipelined_u0_readback(track):
+    """get_u0_async into pinned memory, several steps enqueued without waiting, equals the blocking read-back."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = 70
+    x0 = sample_x0(track, B, seed=12)
+    outs = []
+    for pipelined in (False, True):
+        s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+        s.set_x0(x0); s.init_guess()
+        ring = s.alloc_pinned((5, B, 2)) if pipelined else np.zeros((5, B, 2))
+        for i in range(5):
+            s.step(40.0, model=0, M_sim=25)
+            if pipelined:
+                s.get_u0_async(ring[i])
+            else:
+                ring[i] = s.get_u0()
+        s.synchronize()
+        outs.append(np.array(ring))
+        if pipelined:
+            with pytest.raises(ValueError):
+                s.get_u0_async(np.zeros((B, 3)))
+        s.free()
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 0
