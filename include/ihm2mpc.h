@@ -53,7 +53,8 @@ extern "C" {
 #define IHM2MPC_NYE 8
 #define IHM2MPC_NG 2
 #define IHM2MPC_NLAM 28 /* multipliers per stage: lower (8 bx, 2 bu, 2 g, 2 h) then upper (8, 2, 2, 2) */
-#define IHM2MPC_NMAX 128
+#define IHM2MPC_NMAX 128 /* structural limit; the QP kernel also needs <= 640 constraint slots (two-sided rows with a finite
+                            side, soft sides count separately): N <= 79 with the reference's 8 rows per stage */
 
 #define IHM2MPC_MODEL_FKIN6 0 /* python/models.py:232-307 */
 #define IHM2MPC_MODEL_FDYN6 1 /* python/models.py:455-606 */

@@ -443,9 +443,10 @@ def test_fused_step_equals_the_three_calls(track):
     assert (res[0][4] == 0).sum() >= 0.9 * B
 
 
-@pytest.mark.parametrize("Nh,B", [(2, 5), (3, 9), (5, 70), (33, 65), (64, 64)])
+@pytest.mark.parametrize("Nh,B", [(2, 5), (3, 9), (5, 70), (33, 65), (64, 64), (79, 6)])
 def test_other_horizons_match_oracle(track, Nh, B):
-    """Odd, tiny and long horizons: the streamed sweeps work in pairs / rings of stages and must clamp correctly."""
+    """Odd, tiny and long horizons: the streamed sweeps work in pairs / rings of stages and must clamp correctly.  N = 79 is
+    the longest horizon the slot table takes with the reference's 8 constraint rows per stage (640 slots = 10 per lane)."""
     from ihm2_amd.solver import BatchedOcpSolver
     from oracle import oracle as orc
 
@@ -535,3 +536,45 @@ def test_pipelined_u0_readback(track):
         s.free()
     np.testing.assert_array_equal(outs[0], outs[1])
     assert np.abs(outs[0]).max() > 0
+
+
+def test_several_tracks_in_one_batch_match_oracle():
+    """Per-instance track tables (BASELINE.json configs[3]: Monte-Carlo over the tracks of data/): instance b drives track b mod 3."""
+    from ihm2_amd.solver import BatchedOcpSolver
+    from ihm2_amd.track import track_table
+    from oracle import oracle as orc
+
+    plans = [track_table(t) for t in ("fsds_competition_1", "fsds_competition_2", "fsds_default")]
+    s_ref = np.stack([p.s_ref for p in plans]); k_ref = np.stack([p.kappa_ref for p in plans])
+    B = 66
+    tid = (np.arange(B) % 3).astype(np.int32)
+    ocp = make_ocp()
+    s = BatchedOcpSolver(ocp, B, s_ref, k_ref, track_id=tid)
+    P = orc.OracleProblem(ocp.flatten().as_dict(s_ref, k_ref))
+    x0 = np.zeros((B, 8))
+    for t, p in enumerate(plans):
+        x0[tid == t] = sample_x0(p, int((tid == t).sum()), seed=40 + t)
+    s.set_x0(x0); s.init_guess()
+    x, u = s.get_x(), s.get_u()
+    s.linearize()
+    A, Bm, b = s.get_linearization()
+    Ao, Bo, bo = P.linearize(x, u, track_id=tid)
+    assert np.max(np.abs(A - Ao) / np.maximum(np.abs(Ao).max(axis=2, keepdims=True), 1e-30)) < 1e-10
+    assert np.max(np.abs(b - bo)) < 1e-11
+    # the curvature tables differ: linearising everything on track 0 must NOT reproduce the result
+    A0, _, _ = P.linearize(x, u, track_id=np.zeros(B, dtype=np.int32))
+    assert np.max(np.abs(A0[tid != 0] - Ao[tid != 0])) > 1e-6
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+    s.set_yref(yref); s.set_yref_e(yref_e); s.set_multipliers(None, None)
+    status = s.solve()
+    out = P.rti_step(x, u, x0, yref, yref_e, track_id=tid)
+    np.testing.assert_array_equal(status, out["status"])
+    ok = status == 0
+    assert ok.sum() >= 0.9 * B
+    assert _rel(s.get_x()[ok], x[ok]) < 1e-7 and _rel(s.get_u()[ok], u[ok]) < 1e-7        # tolerance 1e-7 relative
+    # and the plant of every instance runs on its own track
+    xn = s.sim_step(x0, u[:, 0].copy(), model=0, M_sim=25)
+    xo = P.sim_step(x0, u[:, 0].copy(), 0, 25, track_id=tid)
+    assert _rel(xn, xo) < 1e-11
+    s.free()
