@@ -174,7 +174,7 @@ __device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
 // DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  A register ring holds the next D records (lane e
 // keeps elements e and 64+e of each); the record of the next stage is written to the other LDS slot at
 // the top of a stage, so a load is consumed D-1 stages after it was issued.
-// body(k, rec) must end with WSYNC().
+// body(k, rec of stage k, rec of the stage that follows in the sweep, first step) must end with WSYNC().
 template <int DIR, int D, typename F>
 __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2, int N, int lane, F &&body)
 {
@@ -206,7 +206,7 @@ __device__ __forceinline__ void stream_sweep(const double *linb, double *stage2,
             if (s < N) {
                 nxt[lane] = na;
                 if (lane < 24) nxt[64 + lane] = nb;
-                body(k, cur);
+                body(k, cur, nxt, s == 0);
             }
         }
     }
@@ -274,6 +274,11 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     // for all stages, python/mpc.py:49-99).  They are then kept in LDS (H only where the budget of 40 KB per instance allows)
     // instead of being fetched through L2 with lane-dependent addresses in every phase.
     constexpr bool HL = UNI && !PATH, CL = UNI;
+    // FUSED (all-hard tables without track rows, i.e. the reference's OCP): the streamed part of the residuals rides on the
+    // factor sweep, which reads the same records -- one pass over the records less per iteration, its instructions fill the
+    // stalls of the Riccati chain; the convergence test then comes after the factorisation (one is wasted per solve).  The
+    // other instantiations keep the separate residual pass.
+    constexpr bool FUSED = (NSOFT == 0) && !PATH;
 
     // ---- LDS carve-up (doubles) ----
     double *z = sm;                  // NS*10  QP iterate
@@ -520,67 +525,71 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             gt[e] = acc;
         }
-/*@S:2*/
-        // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
-        // between stages).  Branch-free: every lane forms one product of each 8x8 part and the 8-term sums
-        // are DPP reductions -- lane (o, l): A[l][o] pi_{k+1}[l] (column o of A) and A[o][l] z_k[l] (row o).
-        // Stages are independent here: two per step (the 4 staging slots overlay stage2 | Pn | Ws | Gs, which only the
-        // factor sweep uses), all LDS reads of both before any write.
-        {
-            const int o = lane >> 3, l = lane & 7;
-            const double m_l2 = (l < 2) ? 1.0 : 0.0, m_o2 = (o < 2) ? 1.0 : 0.0;
-            stream_pairs<2>(linb, stage2, N, lane, [&](int k, const double *AB0, const double *AB1, bool two) {
-                const double *ABq[2] = {AB0, AB1};
-                double tp[2], tz[2], bp[2], rbv[2];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const double *AB = ABq[q];
-                    const int kq = k + q;
-                    const int kn = min(kq + 1, N);              // stays inside pi / z for the clamped duplicate of an odd tail
-                    const double pl = pi[kn * 8 + l];
-                    tp[q] = sum8(AB[l * 8 + o] * pl);
-                    // row o of [A B] times z_k: lanes l < 2 carry the two input columns as a second product (all lanes
-                    // read, a 0/1 factor selects: cheaper than an exec-mask branch on a single wave)
-                    tz[q] = sum8(fma(AB[64 + o * 2 + (l & 1)] * m_l2, z[kq * 10 + 8 + (l & 1)], AB[o * 8 + l] * z[kq * 10 + l]));
-                    // B' pi_{k+1}: lanes (o < 2, l) hold B[l][o] pi[l]
-                    bp[q] = sum8(AB[64 + l * 2 + (o & 1)] * pl * m_o2);
-                    rbv[q] = tz[q] + AB[80 + o] - z[kn * 10 + o];
-                }
-                if (l == 0) {
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        if (q == 1 && !two) continue;
-                        const int kq = k + q;
-                        gt[kq * 10 + o] += tp[q];
-                        rb[kq * 8 + o] = rbv[q];
-                        if (o < 2) gt[kq * 10 + 8 + o] += bp[q];
-                    }
-                }
-                WSYNC();
-            });
-        }
-/*@S:3*/
-        // (iii) masks and norms
-        res_g = 0.0; res_b = 0.0;
-        for (int e = lane; e < NS * 10; e += 64) {
-            const int k = e / 10, j = e % 10;
-            double v = gt[e];
-            if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
-            res_g = nanmax(res_g, fabs(v));
-        }
-        for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e]));
-        res_g = nanmax(res_g, res_gs);
-        res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m);
-        mu = wave_sum(mu_acc) * inv_m;
-        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; }
-        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; }
-        if (it >= a.iter_max) { qstatus = 1; break; }
+#define NORMS_AND_CHECK() \
+ \
+        res_g = 0.0; res_b = 0.0; \
+        for (int e = lane; e < NS * 10; e += 64) { \
+            const int k = e / 10, j = e % 10; \
+            double v = gt[e]; \
+            if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; } \
+            res_g = nanmax(res_g, fabs(v)); \
+        } \
+        for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e])); \
+        res_g = nanmax(res_g, res_gs); \
+        res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m); \
+        mu = wave_sum(mu_acc) * inv_m; \
+        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; } \
+        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; } \
+        if (it >= a.iter_max) { qstatus = 1; break; } \
         WSYNC();
-
+        if (!FUSED) {
+    /*@S:2*/
+            // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
+            // between stages).  Branch-free: every lane forms one product of each 8x8 part and the 8-term sums
+            // are DPP reductions -- lane (o, l): A[l][o] pi_{k+1}[l] (column o of A) and A[o][l] z_k[l] (row o).
+            // Stages are independent here: two per step (the 4 staging slots overlay stage2 | Pn | Ws | Gs, which only the
+            // factor sweep uses), all LDS reads of both before any write.
+            {
+                const int o = lane >> 3, l = lane & 7;
+                const double m_l2 = (l < 2) ? 1.0 : 0.0, m_o2 = (o < 2) ? 1.0 : 0.0;
+                stream_pairs<2>(linb, stage2, N, lane, [&](int k, const double *AB0, const double *AB1, bool two) {
+                    const double *ABq[2] = {AB0, AB1};
+                    double tp[2], tz[2], bp[2], rbv[2];
+    #pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const double *AB = ABq[q];
+                        const int kq = k + q;
+                        const int kn = min(kq + 1, N);              // stays inside pi / z for the clamped duplicate of an odd tail
+                        const double pl = pi[kn * 8 + l];
+                        tp[q] = sum8(AB[l * 8 + o] * pl);
+                        // row o of [A B] times z_k: lanes l < 2 carry the two input columns as a second product (all lanes
+                        // read, a 0/1 factor selects: cheaper than an exec-mask branch on a single wave)
+                        tz[q] = sum8(fma(AB[64 + o * 2 + (l & 1)] * m_l2, z[kq * 10 + 8 + (l & 1)], AB[o * 8 + l] * z[kq * 10 + l]));
+                        // B' pi_{k+1}: lanes (o < 2, l) hold B[l][o] pi[l]
+                        bp[q] = sum8(AB[64 + l * 2 + (o & 1)] * pl * m_o2);
+                        rbv[q] = tz[q] + AB[80 + o] - z[kn * 10 + o];
+                    }
+                    if (l == 0) {
+    #pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            if (q == 1 && !two) continue;
+                            const int kq = k + q;
+                            gt[kq * 10 + o] += tp[q];
+                            rb[kq * 8 + o] = rbv[q];
+                            if (o < 2) gt[kq * 10 + 8 + o] += bp[q];
+                        }
+                    }
+                    WSYNC();
+                });
+            }
+/*@S:3*/
+            NORMS_AND_CHECK()
+        }
         // separate step lengths for the primal (z, t, s) and the dual (pi, lam, lam_s) variables, as HPIPM's split_step
         double alpha = 1.0, alpha_d = 1.0, sigma = 0.0;
-        for (int pass = 0; pass < 2; pass++) {
 /*@S:4*/
+        // ---- barrier weights and gradient coefficients of the owned slots -> LDS (pass 0: predictor; pass 1: corrector) ----
+        auto slot_coeffs = [&](int pass) {
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
             for (int e = lane; e < NS * NCK; e += 64) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
             WSYNC();
@@ -615,6 +624,9 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 SLOT_ACC(cf[s_kc[r]], c);
             }
             WSYNC();
+        };
+        // modified gradient: gt += R' cf (pass 1 adds its increment on top of the predictor's gradient)
+        auto add_coeffs = [&]() {
             for (int e = lane; e < NS * 10; e += 64) {
                 const int k = e / 10, j = e % 10;
                 double acc = gt[e] + cf[k * NCK + j];
@@ -630,9 +642,13 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
             }
             WSYNC();
 
+        };
+        slot_coeffs(0);
+        if (!FUSED) add_coeffs();          // FUSED: after the norms below (the convergence test needs the unmodified residual)
 /*@S:5*/
-            // ---- factorisation (pass 0 only): P_k, K_k, Guu^-1, P_{k+1} rb_k ----
-            if (pass == 0) {
+            // ---- factorisation: P_k, K_k, Guu^-1, M_k, P_{k+1} rb_k (FUSED: plus the streamed residual terms, one stage ahead
+            // of the Riccati step that needs rb, from the record staged for the next step) ----
+            {
                 {   // terminal stage
                     const int i = lane >> 3, j = lane & 7;
                     double v = HS(N, i, j);
@@ -655,7 +671,27 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 double rc1i = CDV(N - 1, 1, gi), rc1j = CDV(N - 1, 1, gj);
                 // second product of the W phase: lanes 0..15 -> B part of W, lanes 16..23 -> P_{k+1} rb_k
                 const int i2 = (lane < 16) ? (lane >> 1) : ((lane < 24) ? lane - 16 : 0);
-                stream_sweep<-1, 4>(linb, stage2, N, lane, [&](int k, const double *AB) {
+                // streamed residual terms of one stage from its record (FUSED): lane (o, l) forms A[l][o] pi_{k+1}[l], A[o][l] z_k[l]
+                // (+ the two input columns on lanes l < 2) and, for o < 2, B[l][o] pi_{k+1}[l]; three DPP sums
+                const int ro = lane >> 3, rl = lane & 7;
+                const double rm_l2 = (rl < 2) ? 1.0 : 0.0, rm_o2 = (ro < 2) ? 1.0 : 0.0;
+                auto resid = [&](int kq, const double *R) {
+                    const double pl = pi[(kq + 1) * 8 + rl];
+                    const double tp = sum8(R[rl * 8 + ro] * pl);
+                    const double tz = sum8(fma(R[64 + ro * 2 + (rl & 1)] * rm_l2, z[kq * 10 + 8 + (rl & 1)], R[ro * 8 + rl] * z[kq * 10 + rl]));
+                    const double bp = sum8(R[64 + rl * 2 + (ro & 1)] * pl * rm_o2);
+                    const double rbv = tz + R[80 + ro] - z[(kq + 1) * 10 + ro];
+                    if (rl == 0) {
+                        gt[kq * 10 + ro] += tp;
+                        rb[kq * 8 + ro] = rbv;
+                        if (ro < 2) gt[kq * 10 + 8 + ro] += bp;
+                    }
+                };
+                stream_sweep<-1, 4>(linb, stage2, N, lane, [&](int k, const double *AB, const double *ABn, bool first) {
+                    if (FUSED) {
+                        if (first) resid(k, AB);
+                        if (k > 0) resid(k - 1, ABn);
+                    }
                     const double Hk = regH, c0i = rc0i, c0j = rc0j, c1i = rc1i, c1j = rc1j;
                     if (!UNI && k > 0) {        // stage-dependent data: this lane's entries, fetched one stage ahead
                         regH = a.Hs[((k - 1) * 10 + gi) * 10 + gj];
@@ -724,6 +760,14 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
                 });
             }
 
+        if (FUSED) {
+            NORMS_AND_CHECK()
+        }
+#undef NORMS_AND_CHECK
+        for (int pass = 0; pass < 2; pass++) {
+            const double mu_t = fmax(sigma * mu, mu_floor);
+            if (pass == 1) slot_coeffs(1);
+            if (FUSED || pass == 1) add_coeffs();
 /*@S:6*/
             // ---- vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) ----
             // the part without p_{k+1} for all stages in parallel ...
