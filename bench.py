@@ -139,6 +139,7 @@ def main():
     x0 = sample_x0(track, B, seed=20240607 + rank)
     solver.set_x0(x0)
     solver.init_guess()
+    solver.set_lap_wrap(True)        # any number of steps: cars that complete a lap are moved back by one lap length
 
     SYNC_EVERY = 8
     u0_ring = solver.alloc_pinned((SYNC_EVERY, B, 2))      # pinned host memory: u0 of every step is read back in stream order

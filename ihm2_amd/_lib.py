@@ -74,6 +74,7 @@ SYMBOLS = {
     "ihm2mpc_sim_advance": (C.c_int, [_H, C.c_int32, C.c_int32]),
     "ihm2mpc_step": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double]),
     "ihm2mpc_set_active": (C.c_int, [_H, c_int32_p]),
+    "ihm2mpc_set_lap_wrap": (C.c_int, [_H, C.c_int32]),
     "ihm2mpc_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "ihm2mpc_host_free": (C.c_int, [C.c_void_p]),
     "ihm2mpc_get_u0_async": (C.c_int, [_H, c_double_p]),

@@ -489,6 +489,7 @@ int ihm2mpc_reinit_failed(ihm2mpc_handle *h, double v_ref_scale)
 int ihm2mpc_prepare_step(ihm2mpc_handle *h, double s_target)
 {
     CHECK_H(h);
+    if (h->lap_wrap) ihm2_launch_wrap_lap(h);
     ihm2_launch_prepare(h, s_target, 3, h->stream);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -654,6 +655,13 @@ int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst)
     return 0;
 }
 
+int ihm2mpc_set_lap_wrap(ihm2mpc_handle *h, int32_t enable)
+{
+    CHECK_H(h);
+    h->lap_wrap = enable != 0;
+    return 0;
+}
+
 int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active)
 {
     CHECK_H(h);
@@ -673,6 +681,7 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     // The plant step and the reference ramp only feed the QP (through x0 and yref); the warm-start shift and the
     // linearisation only need the previous iterate.  Two branches, joined in front of the QP kernel.
+    if (h->lap_wrap) ihm2_launch_wrap_lap(h);
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));

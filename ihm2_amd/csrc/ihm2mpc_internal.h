@@ -76,6 +76,7 @@ struct ihm2mpc_handle {
     int32_t *status, *qp_iter;   // (B)
     int32_t *active;             // (B) plant mask of the device-resident closed loop (nullptr-equivalent while !active_set)
     bool active_set;
+    bool lap_wrap;               // prepare_step / step move cars that passed s = L back by one lap first
     double *u0;     // (B,2) first control of the last solve
 
     double *lin;    // (B,N,88) linearisation records [A | B | b]
@@ -89,6 +90,7 @@ struct ihm2mpc_handle {
 // --- launchers (each defined in one .hip file) ---
 // mode: bit 0 = reference ramp (needs x0), bit 1 = warm-start shift
 void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream);
+void ihm2_launch_wrap_lap(ihm2mpc_handle *h);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits

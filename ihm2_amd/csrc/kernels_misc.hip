@@ -47,6 +47,20 @@ __global__ __launch_bounds__(64) void k_prepare(int B, int N, double s_target, i
     }
 }
 
+// Lap wrap for closed loops that run longer than the track tables reach (three laps, s in [-L, 2L)): an instance whose car
+// has passed s = L is moved back by one lap -- x0 and the s-component of its whole iterate -- which changes nothing physically
+// (the tables are periodic) and keeps s inside the table for ever.  L = -s_ref[0] of the instance's track (Track::length).
+__global__ __launch_bounds__(64) void k_wrap_lap(int B, int N, int nknots, const double *__restrict__ s_ref, const int32_t *__restrict__ track_id,
+                                                 double *__restrict__ x0, double *__restrict__ x)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
+    const double L = -s_ref[(size_t)track_id[b] * nknots];
+    if (!(x0[(size_t)b * 8] >= L)) return;            // wave-uniform
+    for (int k = lane; k <= N; k += 64) x[((size_t)b * (N + 1) + k) * 8] -= L;
+    if (lane == 0) x0[(size_t)b * 8] -= L;
+}
+
 // MODEL: the model the rollout integrates -- the OCP's own model where that is usable as a simulator (fkin6, fdyn6u), the
 // kinematic one for fdyn6 as written (open-loop unstable over the horizon).
 // only_failed != nullptr: re-initialise only the instances whose last status is non-zero, and clear their multipliers.
@@ -116,6 +130,11 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
 }
 
 }  // namespace
+
+void ihm2_launch_wrap_lap(ihm2mpc_handle *h)
+{
+    hipLaunchKernelGGL(k_wrap_lap, dim3(h->B), dim3(64), 0, h->stream, h->B, h->N, h->cfg.nknots, h->s_ref, h->track_id, h->x0, h->x);
+}
 
 void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream)
 {

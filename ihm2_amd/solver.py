@@ -321,6 +321,10 @@ class BatchedOcpSolver:
             raise ValueError("out must be a C-contiguous float64 (B, 2) array from alloc_pinned")
         _lib.check(self.lib.ihm2mpc_get_u0_async(self._h, _ptr(out)))
 
+    def set_lap_wrap(self, enable: bool = True):
+        """Keep endless closed loops inside the three-lap track tables: cars past ``s = L`` are moved back by one lap."""
+        _lib.check(self.lib.ihm2mpc_set_lap_wrap(self._h, int(bool(enable))))
+
     def set_active(self, active=None):
         """Plant mask for ``sim_advance`` / ``step``: instances with ``active[b] == 0`` keep their ``x0``; ``None`` = all."""
         if active is None:

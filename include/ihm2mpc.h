@@ -182,6 +182,10 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
 /* plant mask (B) for sim_advance / step: an instance with active[b] == 0 keeps its x0 (a car that failed or finished its lap is
  * frozen, as the reference's loop stops, python/main.py:503-517); NULL = all active */
 int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active);
+/* closed loops longer than the three laps the track tables hold (python/motion_planning.py:405-430): with enable != 0,
+ * prepare_step / step first move every car that has passed s = L (L = -s_ref[0], Track::length) back by one lap -- x0 and the
+ * s-component of its iterate.  Off by default: the reference's loop stops one metre after a lap (python/main.py:514-517). */
+int ihm2mpc_set_lap_wrap(ihm2mpc_handle *h, int32_t enable);
 /* pipelined read-back: u0 (B,2) of the last solve is copied to PINNED host memory (ihm2mpc_host_alloc) in stream order, without
  * waiting -- the next ihm2mpc_step can be enqueued at once; the data is valid after ihm2mpc_synchronize (or any blocking getter) */
 int ihm2mpc_host_alloc(uint64_t nbytes, void **p);

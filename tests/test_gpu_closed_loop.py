@@ -96,3 +96,35 @@ def test_device_resident_loop_equals_the_host_loop(track):
     np.testing.assert_allclose(d.x[:n][live], h.x[:n][live], rtol=0, atol=1e-9)        # same kernels, same order: agreement to rounding
     np.testing.assert_allclose(d.u[:n][live], h.u[:n][live], rtol=0, atol=1e-7)
     assert (~h.alive).any() and h.alive.any()              # the batch contains frozen and running cars: the mask is exercised
+
+
+def test_lap_wrap_keeps_an_endless_loop_on_the_track_tables(track):
+    """Cars started near the end of the lap cross s = L: with the lap wrap they are moved back by one lap (x0 and the iterate),
+    the controls are the ones of the unwrapped run (the tables are periodic) and s stays below L + one step."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B, steps = 24, 60
+    L = track.lap_length
+    x0 = sample_x0(track, B, seed=4)
+    x0[:, 0] = L - np.linspace(2.0, 30.0, B); x0[:, 3] = 10.0
+    x0[:, 5] = x0[:, 3] * np.interp(x0[:, 0], track.s_ref, track.kappa_ref)
+    hist = {}
+    for wrap in (False, True):
+        s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+        s.set_lap_wrap(wrap)
+        s.set_x0(x0); s.init_guess()
+        u_hist, s_hist, ok = [], [], np.ones(B, dtype=bool)
+        for _ in range(steps):
+            s.step(40.0, model=0, M_sim=25)
+            u_hist.append(s.get_u0()); s_hist.append(s.get_x0()[:, 0])
+            ok &= s.get_status() == 0
+        hist[wrap] = (np.array(u_hist), np.array(s_hist), s.get_x()[:, :, 0], ok)
+        s.free()
+    ok = hist[False][3] & hist[True][3]
+    assert ok.sum() >= 0.8 * B and np.array_equal(hist[False][3], hist[True][3])      # an occasional infeasible QP, the same on both sides
+    (u0, s0, _), (u1, s1, xs1) = [tuple(a[:, ok] if a.ndim == 2 and a.shape[1] == B else a[ok] if a.shape[0] == B else a[:, ok] for a in h[:3]) for h in (hist[False], hist[True])]
+    assert s0.max() > L + 20.0                          # the cars do cross the line
+    assert s1.max() < L + 1.0                           # wrapped: back by one lap at the next step
+    np.testing.assert_allclose(np.where(s0 >= L + 1.0, s0 - L, s0)[-1], np.where(s1 >= L, s1 - L, s1)[-1], atol=1e-6)
+    assert np.max(np.abs(u0 - u1) / (1.0 + np.abs(u0))) < 1e-6      # same controls up to the rounding of s - L
+    assert np.all(np.abs(xs1[:, 0] - s1[-1]) < 2.0)                   # the iterate moved with x0
