@@ -216,7 +216,7 @@ def main():
         value = total_solves / elapsed
         n_ipm = float(np.mean(qp_iters))
         f_lin, f_qp = flops_per_solve(n_ipm)
-        ms_lin, ms_qp = t_lin / n_timed, t_qp / n_timed
+        ms_lin, ms_qp = t_lin / max(n_timed, 1), t_qp / max(n_timed, 1)
         if ms_lin >= ms_qp:
             kname, kms, kflops = "k_linearize", ms_lin, f_lin * B
         else:
