@@ -249,7 +249,8 @@ def main():
                                  "peak; achieved = algorithmic flops (SURVEY.md 8d model) / HIP-event kernel time",
                          "kernel_ms": kms, "linearize_ms": ms_lin, "qp_ms": ms_qp, "n_ipm_mean": n_ipm, "M": M_SUB,
                          "alg_flops_per_solve": f_lin + f_qp,
-                         "hbm_fraction_algorithmic": alg_bytes * value / world / 1e9 / HBM_PEAK_GBS},
+                         "hbm_fraction_algorithmic": alg_bytes * value / world / 1e9 / HBM_PEAK_GBS,
+                         "hbm_fraction_executed": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
             "latency_ms_p50_batch": float(np.percentile(step_ms, 50)), "latency_ms_p99_batch": float(np.percentile(step_ms, 99)),
             "status_counts": {str(k): int(v) for k, v in enumerate(np.bincount(status_all, minlength=5)) if v},
             "gather_ms": gather_ms,
