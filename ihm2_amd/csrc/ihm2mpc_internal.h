@@ -22,6 +22,7 @@
 #define NC 14   // two-sided constraint rows per stage: 8 state boxes, 2 input boxes, 2 general rows, 2 track rows
 #define NLAM 28
 #define MAX_SLOTS 640   // 10 per lane
+#define QM_PAD 16    // >= 2 x ring depth of the vector / forward sweeps: their unclamped prefetch overshoots an instance by < 2 D rows
 #define LIN_REC 88   // doubles per (instance, interval) linearisation record: A (64) | B (16) | b (8)
 
 struct ihm2mpc_handle {
@@ -83,7 +84,8 @@ struct ihm2mpc_handle {
     // ---- QP workspace in HBM/L2 (everything else of the QP lives in LDS / registers) ----
     double *q_g;    // (B,NS,10) QP gradient
     double *q_P;    // (B,NS,64) Riccati matrices of the current factorisation
-    double *q_M;    // (B,N,64) closed-loop matrices A - B K (row-major; the vector recursion reads them transposed)
+    double *q_M;    // (QM_PAD + B*N + QM_PAD, 64) closed-loop matrices A - B K (row-major; the vector recursion reads them
+                    // transposed), padded at both ends: the sweeps' prefetch rings run QM_PAD rows past an instance unclamped
     double *scratch;   // (B, 3*8) plant scratch
 };
 

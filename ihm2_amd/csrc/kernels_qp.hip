@@ -137,13 +137,17 @@ __device__ __forceinline__ double sum_stride8(double v)
 template <int DIR, int D, int DL, typename P, typename F>
 __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_even, int e_odd, P &&pre, F &&body)
 {
-    static_assert(D % 2 == 0 && DL % 2 == 0 && D % DL == 0, "the element index alternates with the step parity");
+    static_assert(D % 2 == 0 && DL % 2 == 0 && D % DL == 0 && 2 * D <= QM_PAD, "the element index alternates with the step parity");
+    // The prefetches run UNCLAMPED past the instance, by at most ceil(N/D) D + D - N < 2 D rows (D + DL stages of LDS
+    // operands): the streamed array is padded by QM_PAD >= 2 D rows at both ends and the LDS operands sit inside the kernel's LDS carve-up with other arrays on both sides,
+    // so every address is valid and the values fetched for stages outside [0, N) are never used.  (Clamping the indices
+    // cost a third of the sweep's instructions in scalar min / shift / add chains.)
     double r[D], x0[DL], x1[DL];
+    const double *p_even = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_even, *p_odd = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_odd;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const int sd = min(d, N - 1);
-        r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sd : sd) * 64 + ((d & 1) ? e_odd : e_even)];
-        if (d < DL) pre((DIR < 0) ? N - 1 - sd : sd, (d & 1) != 0, x0[d], x1[d]);
+        r[d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * d * 64];
+        if (d < DL) pre((DIR < 0) ? N - 1 - d : d, (d & 1) != 0, x0[d], x1[d]);
     }
     for (int s0 = 0; s0 < N; s0 += D) {
 #pragma unroll
@@ -151,10 +155,8 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
             const int s = s0 + d;
             const int k = (DIR < 0) ? N - 1 - s : s;
             const double v = r[d], y0 = x0[d % DL], y1 = x1[d % DL];
-            const int sn = min(s + D, N - 1);          // unconditional, clamped (see stream_sweep)
-            r[d] = rows[(size_t)((DIR < 0) ? N - 1 - sn : sn) * 64 + ((d & 1) ? e_odd : e_even)];
-            const int sl = min(s + DL, N - 1);
-            pre((DIR < 0) ? N - 1 - sl : sl, (d & 1) != 0, x0[d % DL], x1[d % DL]);
+            r[d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * (s + D) * 64];
+            pre((DIR < 0) ? k - DL : k + DL, (d & 1) != 0, x0[d % DL], x1[d % DL]);
             if (s < N) body(k, v, (d & 1) != 0, y0, y1);
         }
     }
@@ -1005,15 +1007,30 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 
 }  // namespace
 
+// This file is compiled TWICE (Makefile): QP_SET = 0 holds the all-hard instantiations (the reference's OCP), built with LLVM's
+// iterative ILP scheduler (-5 %); QP_SET = 1 holds the soft / track-row instantiations, built with the default scheduler:
+// under the ILP scheduler the instantiation <8,3,1,1> returned wrong statuses for some (correct) source variants -- it spills
+// ~1 KB per lane -- while the default scheduler has been right for every variant.
+#ifndef QP_SET
+#error "compile with -DQP_SET=0 (all-hard instantiations) or -DQP_SET=1 (soft / track-row instantiations)"
+#endif
+#if QP_SET == 0
+int ihm2_launch_qp_hard(ihm2mpc_handle *h)
+#else
+int ihm2_launch_qp_hard(ihm2mpc_handle *h);
 int ihm2_launch_qp(ihm2mpc_handle *h)
+#endif
 {
+#if QP_SET == 1
+    if (!h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8) return ihm2_launch_qp_hard(h);
+#endif
     QpArgs a;
     a.B = h->B; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max; a.nslots = h->nslot_lane * 64; a.m_act = h->m_act;
     a.tol = h->cfg.ipm_tol; a.mu0 = h->cfg.ipm_mu0; a.tau0 = h->cfg.ipm_tau0;
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M;
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
     const int N = h->N, NS = h->NS;
     const int nck = h->path_on ? 14 : 12;
     const int uni = h->uniform_H && h->uniform_CD;
@@ -1033,10 +1050,13 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
             hipLaunchKernelGGL((k_qp_wave<NS_, NO_, PT_, 0>), dim3(h->B), dim3(64), lds, h->stream, a);                   \
         }                                                                                                                 \
     } while (0)
+#if QP_SET == 0
+    if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0, 0);
+    else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0, 0);
+    else return 2;
+#else
     if (!h->path_on) {
-        if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0, 0);
-        else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0, 0);
-        else if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 0);
+        if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 0);
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 0);
         else return 2;
     } else {
@@ -1045,6 +1065,7 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 1);
         else return 2;
     }
+#endif
 #undef LAUNCH_QP
     return 0;
 }
