@@ -54,6 +54,8 @@ SYMBOLS = {
     "ihm2mpc_reinit_failed": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_prepare_step": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_solve": (C.c_int, [_H, C.c_int32]),
+    "ihm2mpc_set_sqp_options": (C.c_int, [_H, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, c_double_p]),
+    "ihm2mpc_get_sqp_stats": (C.c_int, [_H, c_int32_p, c_double_p]),
     "ihm2mpc_linearize": (C.c_int, [_H]),
     "ihm2mpc_get_linearization": (C.c_int, [_H, c_double_p, c_double_p, c_double_p]),
     "ihm2mpc_get_x": (C.c_int, [_H, c_double_p]),
@@ -64,6 +66,7 @@ SYMBOLS = {
     "ihm2mpc_get_residuals": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_multipliers": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_get_slacks": (C.c_int, [_H, c_double_p]),
+    "ihm2mpc_set_slacks": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_timings": (C.c_int, [_H, c_double_p, C.c_int32]),
     "ihm2mpc_set_x0_device": (C.c_int, [_H, C.c_void_p]),
     "ihm2mpc_get_u0_device": (C.c_int, [_H, C.c_void_p]),

@@ -104,6 +104,8 @@ class IHM2Controller(Controller):
         sim_method_num_steps: int = 25,
         nlp_solver_type: str = "SQP_RTI",
         nlp_solver_max_iter: int = 1,
+        globalization: str = "FIXED_STEP",
+        nlp_tol: float = 1e-6,
         terminal_bounds: str = "reference",
         soft_state_bounds: tuple | None = None,
         track_widths=None,
@@ -161,6 +163,8 @@ class IHM2Controller(Controller):
         opts.tf = Nf * dt
         opts.nlp_solver_type = nlp_solver_type
         opts.nlp_solver_max_iter = nlp_solver_max_iter
+        opts.globalization = globalization              # python/main.py:237 asks "MERIT_BACKTRACKING" of its "SQP" solver
+        opts.nlp_tol = nlp_tol
         opts.sim_method_num_steps = sim_method_num_steps
         ocp.solver_options = opts
         ocp.cost.W, ocp.cost.W_e = default_weights(q_s, q_n, q_psi, q_v_x, q_v_y, q_r, q_T, q_delta, q_s_f, q_n_f, q_psi_f,

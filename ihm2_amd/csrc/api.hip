@@ -149,6 +149,10 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2);
     DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
     DA(xc, B * 8); DA(s_guess, B);
+    DA(Wd, N * 144 + 64); DA(st_lb, NS * NC); DA(st_ub, NS * NC); DA(st_sz, NS * NLAM); DA(st_sZ, NS * NLAM);
+    h->sqp_globalization = 0; h->sqp_use_suff = 0; h->sqp_full_step_dual = 0;
+    h->sqp_alpha_min = 0.05; h->sqp_alpha_red = 0.7; h->sqp_eps = 1e-4;
+    for (int i = 0; i < 4; i++) h->sqp_tol[i] = cfg->nlp_tol;
     h->host_lb = new double[NS * NC]; h->host_ub = new double[NS * NC];
     h->host_sz = new double[NS * NLAM]; h->host_sZ = new double[NS * NLAM];
     for (size_t i = 0; i < NS * NC; i++) { h->host_lb[i] = -INFINITY; h->host_ub[i] = INFINITY; }
@@ -168,7 +172,8 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
-                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch};
+                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
+                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -263,6 +268,7 @@ int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e)
         for (int i = 0; i < 100; i++)
             if (Hs[(size_t)k * 100 + i] != Hs[i]) { h->uniform_H = false; break; }
     if (upload_shared(h, Hs.data(), h->Hs, Hs.size()) || upload_shared(h, Gy.data(), h->Gy, Gy.size())) return -1;
+    if (upload_shared(h, W, h->Wd, (size_t)N * 144) || upload_shared(h, W_e, h->Wd + (size_t)N * 144, 64)) return -1;
     h->weights_set = true;
     return 0;
 }
@@ -321,6 +327,9 @@ static int rebuild_slots(ihm2mpc_handle *h)
             kc[e] = s.kc; slb[e] = s.lb; sub[e] = s.ub; zw[e] = s.zw; Zw[e] = s.Zw;
         }
     h->nslots = total; h->m_act = m_act; h->nslot_lane = per_lane; h->nsoft_lane = soft_lane;
+    if (upload_shared(h, h->host_lb, h->st_lb, (size_t)NS * NC) || upload_shared(h, h->host_ub, h->st_ub, (size_t)NS * NC) ||
+        upload_shared(h, h->host_sz, h->st_sz, (size_t)NS * NLAM) || upload_shared(h, h->host_sZ, h->st_sZ, (size_t)NS * NLAM))
+        return -1;
     if (n) {
         HIP_TRY(hipMemcpyAsync(h->slot_kc, kc.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -433,6 +442,14 @@ int ihm2mpc_set_multipliers(ihm2mpc_handle *h, const double *pi, const double *l
     return 0;
 }
 
+int ihm2mpc_set_slacks(ihm2mpc_handle *h, const double *sl)
+{
+    CHECK_H(h);
+    if (sl) return upload(h, sl, h->slk, h->NS * NLAM);
+    HIP_TRY(hipMemsetAsync(h->slk, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
+    return 0;
+}
+
 int ihm2mpc_set_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const char *field, const double *value, int32_t n)
 {
     CHECK_H(h);
@@ -504,19 +521,91 @@ int ihm2mpc_linearize(ihm2mpc_handle *h)
     return 0;
 }
 
+// SQP mode: buffers of the line search, allocated on first use (36 KB per instance)
+static int sqp_buffers(ihm2mpc_handle *h)
+{
+    if (h->ls_x) return 0;
+    const size_t B = h->B, N = h->N, NS = h->NS;
+#define DA(p, n) if (dalloc(&h->p, (n))) return -1
+    DA(ls_x, B * NS * 8); DA(ls_u, B * N * 2); DA(ls_pi, B * NS * 8); DA(ls_lam, B * NS * NLAM); DA(ls_slk, B * NS * NLAM);
+    DA(ls_wpi, B * NS * 8); DA(ls_wlam, B * NS * NLAM); DA(ls_alpha, B); DA(ls_done, B); DA(ls_status, B); DA(ls_iter, B); DA(ls_qp_acc, B);
+#undef DA
+    return 0;
+}
+
+// SQP mode: n_iter iterations of [copy the iterate aside -> linearise -> QP -> convergence test + line search].  join: the first
+// QP waits for ev_join (ihm2mpc_step runs the plant and the reference ramp beside the first linearisation).
+static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
+{
+    if (sqp_buffers(h)) return -1;
+    const size_t B = h->B, N = h->N, NS = h->NS;
+    HIP_TRY(hipMemsetAsync(h->ls_done, 0, B * sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ls_iter, 0, B * sizeof(int32_t), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ls_qp_acc, 0, B * sizeof(int32_t), h->stream));
+    for (int it = 0; it < n_iter; it++) {
+        // the iterate the QP is built at: the line search walks from it towards the QP's full step
+        HIP_TRY(hipMemcpyAsync(h->ls_x, h->x, B * NS * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->ls_u, h->u, B * N * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->ls_pi, h->pi, B * NS * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->ls_lam, h->lam, B * NS * NLAM * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->ls_slk, h->slk, B * NS * NLAM * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        ihm2_launch_linearize(h);
+        if (it == 0 && join) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        if (it == n_iter - 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+        if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+        ihm2_launch_line_search(h, it, it == n_iter - 1);
+    }
+    return 0;
+}
+
+static int sqp_iter_count(ihm2mpc_handle *h) { return h->cfg.nlp_solver_max_iter > 0 ? h->cfg.nlp_solver_max_iter : 1; }
+
 int ihm2mpc_solve(ihm2mpc_handle *h, int32_t n_iter)
 {
     CHECK_H(h);
     if (ready(h)) return -1;
-    if (n_iter <= 0) n_iter = (h->cfg.nlp_solver_type == IHM2MPC_SQP) ? (h->cfg.nlp_solver_max_iter > 0 ? h->cfg.nlp_solver_max_iter : 1) : 1;
+    const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
+    if (n_iter <= 0) n_iter = sqp ? sqp_iter_count(h) : 1;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    for (int it = 0; it < n_iter; it++) {
-        ihm2_launch_linearize(h);
-        if (it == n_iter - 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-        if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+    if (sqp) {
+        if (sqp_iterations(h, n_iter, false)) return -1;
+    } else {
+        for (int it = 0; it < n_iter; it++) {
+            ihm2_launch_linearize(h);
+            if (it == n_iter - 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+            if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+        }
     }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ihm2mpc_set_sqp_options(ihm2mpc_handle *h, int32_t globalization, double alpha_min, double alpha_reduction, double eps_sufficient_descent,
+                            int32_t use_sufficient_descent, int32_t full_step_dual, const double *tol)
+{
+    CHECK_H(h);
+    if (globalization != IHM2MPC_FIXED_STEP && globalization != IHM2MPC_MERIT_BACKTRACKING) return fail("unknown globalization %d", globalization);
+    if (!(alpha_min > 0.0 && alpha_min <= 1.0)) return fail("alpha_min must be in (0, 1]");
+    if (!(alpha_reduction > 0.0 && alpha_reduction < 1.0)) return fail("alpha_reduction must be in (0, 1)");
+    if (!(eps_sufficient_descent >= 0.0 && eps_sufficient_descent < 1.0)) return fail("eps_sufficient_descent must be in [0, 1)");
+    h->sqp_globalization = globalization; h->sqp_alpha_min = alpha_min; h->sqp_alpha_red = alpha_reduction; h->sqp_eps = eps_sufficient_descent;
+    h->sqp_use_suff = use_sufficient_descent ? 1 : 0; h->sqp_full_step_dual = full_step_dual ? 1 : 0;
+    if (tol)
+        for (int i = 0; i < 4; i++) {
+            if (!(tol[i] >= 0.0)) return fail("tolerance %d is negative", i);
+            h->sqp_tol[i] = tol[i];
+        }
+    return 0;
+}
+
+int ihm2mpc_get_sqp_stats(ihm2mpc_handle *h, int32_t *sqp_iter, double *alpha)
+{
+    CHECK_H(h);
+    if (!h->ls_x) return fail("no SQP-mode solve has run on this handle");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (sqp_iter) HIP_TRY(hipMemcpy(sqp_iter, h->ls_iter, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (alpha) HIP_TRY(hipMemcpy(alpha, h->ls_alpha, (size_t)h->B * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -689,10 +778,14 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     ihm2_launch_prepare(h, s_target, 1, h->stream2);
     HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
     ihm2_launch_prepare(h, s_target, 2, h->stream);
-    ihm2_launch_linearize(h);
-    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+    if (h->cfg.nlp_solver_type == IHM2MPC_SQP) {
+        if (sqp_iterations(h, sqp_iter_count(h), true)) return -1;
+    } else {
+        ihm2_launch_linearize(h);
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+        if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+    }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(hipGetLastError());
     return 0;

@@ -87,6 +87,16 @@ struct ihm2mpc_handle {
     double *q_M;    // (QM_PAD + B*N + QM_PAD, 64) closed-loop matrices A - B K (row-major; the vector recursion reads them
                     // transposed), padded at both ends: the sweeps' prefetch rings run QM_PAD rows past an instance unclamped
     double *scratch;   // (B, 3*8) plant scratch
+
+    // ---- SQP mode (cfg.nlp_solver_type == IHM2MPC_SQP): convergence test + merit line search, kernels_sqp.hip ----
+    int sqp_globalization, sqp_use_suff, sqp_full_step_dual;   // globalization: 0 FIXED_STEP, 1 MERIT_BACKTRACKING
+    double sqp_alpha_min, sqp_alpha_red, sqp_eps, sqp_tol[4];
+    double *Wd;                     // (N,12,12) then W_e (8,8): the merit function evaluates the cost from the weights themselves
+    double *st_lb, *st_ub;          // (NS,NC) device copies of host_lb / host_ub
+    double *st_sz, *st_sZ;          // (NS,NLAM) device copies of host_sz / host_sZ
+    // allocated by the first SQP solve: the iterate the QP was built at, merit weights, per-solve bookkeeping
+    double *ls_x, *ls_u, *ls_pi, *ls_lam, *ls_slk, *ls_wpi, *ls_wlam, *ls_alpha;
+    int32_t *ls_done, *ls_status, *ls_iter, *ls_qp_acc;
 };
 
 // --- launchers (each defined in one .hip file) ---
@@ -95,6 +105,7 @@ void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream
 void ihm2_launch_wrap_lap(ihm2mpc_handle *h);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
+void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last);
 int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,
                      const int32_t *active);

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64) void k_wrap_lap(int B, int N, int nknots, const
 
 // MODEL: the model the rollout integrates -- the OCP's own model where that is usable as a simulator (fkin6, fdyn6u), the
 // kinematic one for fdyn6 as written (open-loop unstable over the horizon).
-// only_failed != nullptr: re-initialise only the instances whose last status is non-zero, and clear their multipliers.
+// only_failed != nullptr: re-initialise only the instances whose last solve failed (status other than 0 and 2 = max-iter of
+// the SQP mode, as python/main.py:326 accepts), and clear their multipliers.
 template <int MODEL>
 __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double dt, double v_ref_scale, int nknots,
                                                    const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     if (only_failed) {
-        if (only_failed[b] == 0) return;
+        if (only_failed[b] == 0 || only_failed[b] == 2) return;
         for (int e = 0; e < (N + 1) * 8; e++) pi[(size_t)b * (N + 1) * 8 + e] = 0.0;
         for (int e = 0; e < (N + 1) * NLAM; e++) lam[(size_t)b * (N + 1) * NLAM + e] = 0.0;
     }

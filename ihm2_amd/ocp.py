@@ -172,7 +172,16 @@ class AcadosOcpOptions:
     integrator_type: str = "ERK"                  # RK4 x sim_method_num_steps (old/generate.py:23-25)
     sim_method_num_stages: int = 4
     sim_method_num_steps: int = 25                # M; 1 is unstable on this model
-    globalization: str = "FIXED_STEP"
+    globalization: str = "FIXED_STEP"             # or "MERIT_BACKTRACKING" (python/main.py:237); SQP mode only
+    alpha_min: float = 0.05                       # line search (acados' defaults)
+    alpha_reduction: float = 0.7
+    eps_sufficient_descent: float = 1e-4
+    line_search_use_sufficient_descent: int = 0
+    full_step_dual: int = 0
+    nlp_solver_tol_stat: float | None = None      # SQP mode: None -> nlp_tol
+    nlp_solver_tol_eq: float | None = None
+    nlp_solver_tol_ineq: float | None = None
+    nlp_solver_tol_comp: float | None = None
     print_level: int = 0
     # implementation knobs
     qp_solver_iter_max: int = 30
@@ -281,6 +290,13 @@ class OcpData:
     nlp_solver_type: str = "SQP_RTI"
     nlp_solver_max_iter: int = 1
     nlp_tol: float = 1e-6
+    globalization: str = "FIXED_STEP"
+    alpha_min: float = 0.05
+    alpha_reduction: float = 0.7
+    eps_sufficient_descent: float = 1e-4
+    use_sufficient_descent: int = 0
+    full_step_dual: int = 0
+    sqp_tol: np.ndarray = field(default_factory=lambda: np.full(4, 1e-6))   # stat, eq, ineq, comp
     soft_z: np.ndarray | None = None   # (N+1,28) linear slack penalty per one-sided constraint (14 lower, 14 upper)
     soft_Z: np.ndarray | None = None   # (N+1,28) quadratic slack penalty; < 0 = hard side
     path_on: int = 0                   # track-boundary rows h (stages 1..N)
@@ -307,6 +323,8 @@ class OcpData:
             raise ValueError("ERK is the classical 4-stage RK4")
         if o.nlp_solver_type not in ("SQP_RTI", "SQP"):
             raise ValueError(f"nlp_solver_type {o.nlp_solver_type!r}")
+        if o.globalization not in ("FIXED_STEP", "MERIT_BACKTRACKING"):
+            raise ValueError(f"globalization {o.globalization!r}")
         dt = o.tf / N
         lbx = np.full((N + 1, NX), -INF)
         ubx = np.full((N + 1, NX), INF)
@@ -378,6 +396,11 @@ class OcpData:
             ipm_iter_max=int(o.qp_solver_iter_max), ipm_tol=float(o.qp_tol), ipm_mu0=float(o.qp_mu0),
             ipm_tau0=float(o.qp_tau0), nlp_solver_type=o.nlp_solver_type,
             nlp_solver_max_iter=int(o.nlp_solver_max_iter), nlp_tol=float(o.nlp_tol),
+            globalization=o.globalization, alpha_min=float(o.alpha_min), alpha_reduction=float(o.alpha_reduction),
+            eps_sufficient_descent=float(o.eps_sufficient_descent), use_sufficient_descent=int(o.line_search_use_sufficient_descent),
+            full_step_dual=int(o.full_step_dual),
+            sqp_tol=np.array([float(o.nlp_tol) if t is None else float(t) for t in
+                              (o.nlp_solver_tol_stat, o.nlp_solver_tol_eq, o.nlp_solver_tol_ineq, o.nlp_solver_tol_comp)]),
         )
 
     def as_dict(self, s_ref, kappa_ref, track_widths=None) -> dict:

@@ -25,6 +25,7 @@ from .constants import NG, NLAM, NU, NX, NY
 from .ocp import AcadosOcp, AcadosOcpOptions, OcpData
 
 _SOLVER_TYPE = {"SQP_RTI": 0, "SQP": 1}
+_GLOBALIZATION = {"FIXED_STEP": 0, "MERIT_BACKTRACKING": 1}
 
 
 def _f64(a, shape=None, name="array"):
@@ -64,6 +65,9 @@ class BatchedOcpSolver:
         self.set_track_id(np.zeros(self.B, dtype=np.int32) if track_id is None else track_id)
         self._push_weights()
         self._push_bounds()
+        if d.nlp_solver_type == "SQP":
+            self.set_sqp_options(d.globalization, d.alpha_min, d.alpha_reduction, d.eps_sufficient_descent, d.use_sufficient_descent,
+                                 d.full_step_dual, d.sqp_tol)
 
     # ---- lifetime ----
     def free(self):
@@ -193,6 +197,20 @@ class BatchedOcpSolver:
         self.solve_async(n_iter)
         return self.get_status()
 
+    def set_sqp_options(self, globalization="MERIT_BACKTRACKING", alpha_min=0.05, alpha_reduction=0.7, eps_sufficient_descent=1e-4,
+                        use_sufficient_descent=False, full_step_dual=False, tol=None):
+        """Line search and tolerances of the SQP mode (``python/main.py:230-237``); ``tol`` = (stat, eq, ineq, comp) or a scalar."""
+        t = None if tol is None else np.ascontiguousarray(np.broadcast_to(_f64(tol), (4,)))
+        _lib.check(self.lib.ihm2mpc_set_sqp_options(self._h, _GLOBALIZATION[globalization], float(alpha_min), float(alpha_reduction),
+                                                     float(eps_sufficient_descent), int(bool(use_sufficient_descent)), int(bool(full_step_dual)),
+                                                     None if t is None else _ptr(t)))
+
+    def get_sqp_stats(self):
+        """QP solves made (B) and last step length (B) of the last SQP-mode solve."""
+        it = np.empty(self.B, dtype=np.int32); alpha = np.empty(self.B)
+        _lib.check(self.lib.ihm2mpc_get_sqp_stats(self._h, it.ctypes.data_as(_lib.c_int32_p), _ptr(alpha)))
+        return {"sqp_iter": it, "alpha": alpha}
+
     def synchronize(self):
         _lib.check(self.lib.ihm2mpc_synchronize(self._h))
 
@@ -228,6 +246,10 @@ class BatchedOcpSolver:
         pi = np.empty((self.B, self.N + 1, NX)); lam = np.empty((self.B, self.N + 1, NLAM))
         _lib.check(self.lib.ihm2mpc_get_multipliers(self._h, _ptr(pi), _ptr(lam)))
         return pi, lam
+
+    def set_slacks(self, sl=None):
+        """Slack values the next SQP-mode solve starts from, ``(B, N+1, 28)``; ``None`` = zeros."""
+        _lib.check(self.lib.ihm2mpc_set_slacks(self._h, None if sl is None else _ptr(_f64(sl, (self.B, self.N + 1, NLAM), "sl"))))
 
     def get_slacks(self):
         """Slack of each soft constraint side after the last QP, ``(B, N+1, 28)`` (0 for hard sides)."""
@@ -448,8 +470,12 @@ class AcadosOcpSolver:
     def get_stats(self, field: str):
         if field == "residuals":
             return self.batch.get_residuals()[self.i]
-        if field in ("qp_iter", "sqp_iter"):
-            return int(self.batch.get_qp_iter()[self.i]) if field == "qp_iter" else 1
+        if field == "qp_iter":
+            return int(self.batch.get_qp_iter()[self.i])
+        if field in ("sqp_iter", "alpha"):
+            if self.batch.data.nlp_solver_type != "SQP":
+                return 1 if field == "sqp_iter" else 1.0
+            return self.batch.get_sqp_stats()[field][self.i].item()
         if field == "time_tot":
             return self.batch.get_timings()["total_ms"] * 1e-3
         raise Exception(f"AcadosOcpSolver.get_stats(): '{field}' is not a valid argument.")

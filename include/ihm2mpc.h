@@ -17,6 +17,8 @@
  *   ihm2mpc_set_x / _set_u    <- solver.set(j,"x"/"u",..) (warm start)          python/main.py:317-322
  *   ihm2mpc_prepare_step      <- the whole of python/main.py:303-322 on device (reference ramp + shift)
  *   ihm2mpc_solve             <- solver.solve()                                 python/main.py:325; mpc_control_node.cpp:189
+ *   ihm2mpc_set_sqp_options   <- ocp.solver_options.globalization / alpha_min / ... / nlp_solver_tol_*   python/main.py:230-237
+ *   ihm2mpc_get_sqp_stats     <- solver.get_stats("sqp_iter") / ("alpha") (acados)
  *   ihm2mpc_get_x/_u/_u0      <- solver.get(i,"x"/"u")                          python/main.py:331-334; mpc_control_node.cpp:202-206
  *   ihm2mpc_get_status        <- return value of solve()                        python/main.py:325-328; dpc/main.py:287-293
  *   ihm2mpc_get_residuals     <- solver.get_stats("residuals") (acados)
@@ -64,6 +66,8 @@ extern "C" {
 
 #define IHM2MPC_SQP_RTI 0 /* old/generate.py:21 */
 #define IHM2MPC_SQP 1     /* python/main.py:230 */
+#define IHM2MPC_FIXED_STEP 0         /* full steps */
+#define IHM2MPC_MERIT_BACKTRACKING 1 /* python/main.py:237 */
 
 typedef struct ihm2mpc_handle ihm2mpc_handle;
 
@@ -136,15 +140,30 @@ int ihm2mpc_get_stage(ihm2mpc_handle *h, int32_t instance, int32_t stage, const 
 /* ---- the hot path ---- */
 /* initial guess: roll the model out from x0 under a Stanley-type feedback (python/main.py:99-163) */
 int ihm2mpc_init_guess(ihm2mpc_handle *h, double v_ref_scale);
-/* the same rollout for the instances whose last solve failed (status != 0) only, multipliers cleared: a failed instance keeps
+/* the same rollout for the instances whose last solve failed (status other than 0 and 2) only, multipliers cleared: a failed instance keeps
  * its iterate, which can keep it infeasible for ever; the reference stops its single loop instead
  * (python/main.py:326-328).  Call between solve() and the next prepare_step(). */
 int ihm2mpc_reinit_failed(ihm2mpc_handle *h, double v_ref_scale);
 /* reference ramp yref_j = [s0 + s_target*j/N, 0..], yref_e = [s0 + s_target, 0..] from the current
  * x0, and warm-start shift of (x,u) -- python/main.py:303-322 -- entirely on device */
 int ihm2mpc_prepare_step(ihm2mpc_handle *h, double s_target);
-/* n_iter RTI iterations (n_iter <= 0: the configured nlp_solver_max_iter / 1 for SQP_RTI) */
+/* n_iter RTI iterations (n_iter <= 0: the configured nlp_solver_max_iter / 1 for SQP_RTI).
+ * With nlp_solver_type IHM2MPC_SQP (python/main.py:230-237) every iteration first tests the four KKT residuals of the iterate
+ * against the tolerances -- a converged instance gets status 0 and is left alone -- and the QP step is scaled by the line
+ * search chosen with ihm2mpc_set_sqp_options; an instance still iterating after n_iter QPs gets status 2 (ACADOS_MAXITER),
+ * a QP failure ends its solve with status 1 / 4.  get_qp_iter then reports the interior-point iterations of all its QPs. */
 int ihm2mpc_solve(ihm2mpc_handle *h, int32_t n_iter);
+/* SQP mode only.  globalization IHM2MPC_FIXED_STEP (default) or IHM2MPC_MERIT_BACKTRACKING: backtracking on the l1 merit
+ * function  cost + sum w |dynamics defect| + sum w max(0, constraint violation)  with weights following the QP multipliers
+ * (|mult|, then max(|mult|, (w + |mult|)/2)); trial steps alpha = 1, alpha_reduction, alpha_reduction^2, ... >= alpha_min,
+ * accepted on plain decrease or, with use_sufficient_descent, on m(alpha) - m(0) <= eps_sufficient_descent alpha D;
+ * full_step_dual keeps the QP multipliers instead of moving them by alpha.  tol (4): stat, eq, ineq, comp, NULL keeps the
+ * current ones (cfg.nlp_tol for all four).  Defaults: 0.05, 0.7, 1e-4, 0, 0 -- acados' defaults. */
+int ihm2mpc_set_sqp_options(ihm2mpc_handle *h, int32_t globalization, double alpha_min, double alpha_reduction,
+                            double eps_sufficient_descent, int32_t use_sufficient_descent, int32_t full_step_dual,
+                            const double *tol);
+/* QP solves made (B) and the last step length (B) of the last SQP-mode solve; either pointer may be NULL */
+int ihm2mpc_get_sqp_stats(ihm2mpc_handle *h, int32_t *sqp_iter, double *alpha);
 /* phases of solve(), exposed for parity tests and profiling */
 int ihm2mpc_linearize(ihm2mpc_handle *h);
 int ihm2mpc_get_linearization(ihm2mpc_handle *h, double *A, double *Bm, double *b); /* (B,N,8,8),(B,N,8,2),(B,N,8) */
@@ -156,6 +175,8 @@ int ihm2mpc_get_status(ihm2mpc_handle *h, int32_t *status);     /* (B) */
 int ihm2mpc_get_qp_iter(ihm2mpc_handle *h, int32_t *qp_iter);   /* (B) */
 int ihm2mpc_get_residuals(ihm2mpc_handle *h, double *res);      /* (B,4): stat, eq, ineq, comp */
 int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam);
+/* slack values the next SQP-mode solve starts from (its line search walks from them to the QP's); NULL = zeros */
+int ihm2mpc_set_slacks(ihm2mpc_handle *h, const double *sl);     /* (B,N+1,28) */
 int ihm2mpc_get_slacks(ihm2mpc_handle *h, double *sl);         /* (B,N+1,28) slack of each soft side after the last QP */
 /* milliseconds of the last solve(): [0] total, [1] linearize, [2] qp+update (HIP events) */
 int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n);

@@ -134,6 +134,22 @@ void orc_rti_step(const orc_problem *P, int B, double *x, double *u, const doubl
                   const double *yref, const double *yref_e, const int *track_id, double *pi,
                   double *lam, int *status, double *res, int *qp_iter, int nthreads);
 
+/* --- globalised SQP (python/main.py:230-237: "SQP", max_iter 2, "MERIT_BACKTRACKING"): up to max_iter iterations of
+ * [KKT test at the iterate -> QP -> backtracking line search on the l1 merit function -> step alpha on primal and dual];
+ * see ihm2_oracle_rti.c.  globalization 0 = FIXED_STEP (alpha = 1).  sl (B,N+1,28): slack values, in/out (start at 0);
+ * status: 0 converged, 2 max_iter, 4 QP failure, 1 NaN; sqp_iter (B): QP solves made; alpha (B): last step length */
+typedef struct {
+    int max_iter;
+    int globalization;
+    int use_sufficient_descent;
+    int full_step_dual;
+    double tol[4];      /* stat, eq, ineq, comp */
+    double alpha_min, alpha_reduction, eps_sufficient_descent;
+} orc_sqp_opts;
+void orc_sqp_solve(const orc_problem *P, const orc_sqp_opts *O, int B, double *x, double *u, const double *x0,
+                   const double *yref, const double *yref_e, const int *track_id, double *pi, double *lam, double *sl,
+                   int *status, double *res, int *qp_iter, int *sqp_iter, double *alpha, int nthreads);
+
 /* linearisation only: A (B,N,8,8), Bm (B,N,8,2), b (B,N,8) where b = Phi(x_k,u_k) - x_{k+1} */
 void orc_linearize(const orc_problem *P, int B, const double *x, const double *u,
                    const int *track_id, double *A, double *Bm, double *b, int nthreads);

@@ -34,6 +34,12 @@ class _Problem(C.Structure):
     ]
 
 
+class _SqpOpts(C.Structure):
+    """``orc_sqp_opts`` (ihm2_oracle.h)."""
+    _fields_ = [("max_iter", C.c_int), ("globalization", C.c_int), ("use_sufficient_descent", C.c_int), ("full_step_dual", C.c_int),
+                ("tol", C.c_double * 4), ("alpha_min", C.c_double), ("alpha_reduction", C.c_double), ("eps_sufficient_descent", C.c_double)]
+
+
 def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
@@ -207,6 +213,32 @@ class OracleProblem:
                            pi.ctypes.data_as(_dp), lam.ctypes.data_as(_dp), status.ctypes.data_as(_ip),
                            res.ctypes.data_as(_dp), qp_iter.ctypes.data_as(_ip), C.c_int(nthreads))
         return dict(status=status, res=res, qp_iter=qp_iter, pi=pi, lam=lam)
+
+    def sqp_solve(self, x, u, x0, yref, yref_e, track_id=None, pi=None, lam=None, sl=None, max_iter=2, globalization="MERIT_BACKTRACKING",
+                  tol=1e-6, alpha_min=0.05, alpha_reduction=0.7, eps_sufficient_descent=1e-4, use_sufficient_descent=False,
+                  full_step_dual=False, nthreads=0):
+        """Globalised SQP (``orc_sqp_solve``); ``x``, ``u`` (and ``pi``, ``lam``, ``sl`` when given) are updated IN PLACE."""
+        N = self.N
+        assert x.dtype == np.float64 and x.flags.c_contiguous and u.dtype == np.float64 and u.flags.c_contiguous
+        B = x.shape[0]
+        x0, x0p = _d(x0); yref, yp = _d(yref); yref_e, yep = _d(yref_e)
+        tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
+        if pi is None: pi = np.zeros((B, N + 1, NX))
+        if lam is None: lam = np.zeros((B, N + 1, 2 * NC))
+        if sl is None: sl = np.zeros((B, N + 1, 2 * NC))
+        assert pi.flags.c_contiguous and lam.flags.c_contiguous and sl.flags.c_contiguous
+        o = _SqpOpts()
+        o.max_iter = int(max_iter); o.globalization = {"FIXED_STEP": 0, "MERIT_BACKTRACKING": 1}[globalization]
+        o.use_sufficient_descent = int(use_sufficient_descent); o.full_step_dual = int(full_step_dual)
+        for i, t in enumerate(np.broadcast_to(np.asarray(tol, dtype=np.float64), (4,))): o.tol[i] = float(t)
+        o.alpha_min, o.alpha_reduction, o.eps_sufficient_descent = float(alpha_min), float(alpha_reduction), float(eps_sufficient_descent)
+        status = np.zeros(B, dtype=np.int32); res = np.zeros((B, 4)); qp_iter = np.zeros(B, dtype=np.int32)
+        sqp_iter = np.zeros(B, dtype=np.int32); alpha = np.zeros(B)
+        lib().orc_sqp_solve(C.byref(self.p), C.byref(o), C.c_int(B), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp), x0p, yp, yep, tp,
+                            pi.ctypes.data_as(_dp), lam.ctypes.data_as(_dp), sl.ctypes.data_as(_dp), status.ctypes.data_as(_ip),
+                            res.ctypes.data_as(_dp), qp_iter.ctypes.data_as(_ip), sqp_iter.ctypes.data_as(_ip),
+                            alpha.ctypes.data_as(_dp), C.c_int(nthreads))
+        return dict(status=status, res=res, qp_iter=qp_iter, sqp_iter=sqp_iter, alpha=alpha, pi=pi, lam=lam, sl=sl)
 
     def linearize(self, x, u, track_id=None, nthreads=0):
         N = self.N; B = x.shape[0]

@@ -128,3 +128,31 @@ def test_lap_wrap_keeps_an_endless_loop_on_the_track_tables(track):
     np.testing.assert_allclose(np.where(s0 >= L + 1.0, s0 - L, s0)[-1], np.where(s1 >= L, s1 - L, s1)[-1], atol=1e-6)
     assert np.max(np.abs(u0 - u1) / (1.0 + np.abs(u0))) < 1e-6      # same controls up to the rounding of s - L
     assert np.all(np.abs(xs1[:, 0] - s1[-1]) < 2.0)                   # the iterate moved with x0
+
+
+def test_closed_loop_with_the_live_solver_options(track):
+    """python/main.py:230-237: nlp_solver_type "SQP", nlp_solver_max_iter 2, globalization "MERIT_BACKTRACKING" -- the MiL loop
+    runs on them; every solve ends with status 0 or 2 (what python/main.py:326 accepts) and the cars track the centre line at
+    least as well as with one RTI iteration per step."""
+    from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop
+    from ihm2_amd.controller import IHM2Controller
+
+    B, steps = 48, 60
+    x0 = sample_x0(track, B, seed=21)
+    x0[:, 3] = np.linspace(4.0, 12.0, B)
+    out = {}
+    for name, kw in (("rti", {}), ("sqp", dict(nlp_solver_type="SQP", nlp_solver_max_iter=2, globalization="MERIT_BACKTRACKING"))):
+        ctrl = IHM2Controller(track.s_ref, track.kappa_ref, batch_size=B, **kw)
+        sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=40), SimModelVariant.KIN6)
+        ctrl.warm_start(x0)
+        res = run_closed_loop(ctrl, sim, x0, steps, lap_length=None)
+        stats = ctrl.solver.get_sqp_stats() if name == "sqp" else None
+        out[name] = (res, stats)
+        ctrl.solver.free()
+    rti, sqp = out["rti"][0], out["sqp"][0]
+    assert sqp.alive.all() and np.all(np.isin(sqp.status, (0, 2)))
+    assert np.all(out["sqp"][1]["sqp_iter"] <= 2) and np.all(out["sqp"][1]["alpha"] > 0.0)
+    assert np.all(np.isfinite(sqp.x)) and np.all(sqp.x[-1, :, 0] > sqp.x[0, :, 0] + 10.0)
+    both = rti.alive & sqp.alive
+    err = lambda r: np.sqrt(np.mean(r.x[steps // 2:, both, 1] ** 2))        # rms lateral offset over the second half
+    assert err(sqp) <= 1.2 * err(rti) + 0.02

@@ -20,12 +20,15 @@ from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 from ihm2_amd.track import track_table  # noqa: E402
 
 
-def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False, host_state=False):
+def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False, host_state=False,
+                   sqp=None):
     plans = [track_table(t) for t in tracks]
     mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, {"fkin6": O.fkin6_model, "fdyn6": O.fdyn6_model, "fdyn6u": O.fdyn6u_model}[model], 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
     ocp.cost.W, ocp.cost.W_e = O.default_weights()
     ocp.solver_options.tf = 2.0
+    if sqp is not None:         # the live options of python/main.py:230-237: "SQP", max_iter 2, "MERIT_BACKTRACKING"
+        ocp.solver_options.nlp_solver_type, ocp.solver_options.nlp_solver_max_iter, ocp.solver_options.globalization = "SQP", 2, sqp
     if terminal_bounds == "stage":      # see IHM2Controller(terminal_bounds=...): quirk Q1
         c = ocp.constraints
         c.idxbx_e, c.lbx_e, c.ubx_e = c.idxbx.copy(), c.lbx.copy(), c.ubx.copy()
@@ -69,12 +72,15 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
         step()
     solver.synchronize(); t0 = time.perf_counter(); tl = tq = 0.0; n_ok = 0
     for _ in range(steps):
-        step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]; n_ok += int((solver.get_status() == 0).sum())
+        step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]; n_ok += int(np.isin(solver.get_status(), (0, 2) if sqp else (0,)).sum())
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
-    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, sqp=sqp, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
                qp_ms=tq / steps, ok_fraction=n_ok / (B * steps), status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
+    if sqp:
+        ss = solver.get_sqp_stats()
+        out["sqp_iter_mean"] = float(ss["sqp_iter"].mean()); out["alpha_mean"] = float(ss["alpha"].mean()); out["alpha_lt1"] = float((ss["alpha"] < 1.0).mean())
     solver.free()
     return out
 
@@ -98,6 +104,8 @@ if __name__ == "__main__":
     all_tracks = ("fsds_competition_1", "fsds_competition_2", "fsds_competition_3", "fsds_default")
     for fn, kw in ((rti_throughput, dict(model="fkin6", B=1024)), (rti_throughput, dict(model="fkin6", B=1024, host_state=True)),
                    (rti_throughput, dict(model="fkin6", B=8192)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="FIXED_STEP")),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING")),
                    (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage", track_rows="soft")),
