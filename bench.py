@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-step-launches", action="store_true",
+                    help="one launch per phase and step (ihm2mpc_step) instead of the persistent per-instance loop (ihm2mpc_run_steps)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N>1 path on one GPU")
@@ -159,29 +161,64 @@ def main():
             if on_gpu:
                 torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t_lin = t_qp = 0.0
+    persistent = not args.per_step_launches
+    t_lin = t_qp = t_loop = 0.0
     n_timed = 0
-    qp_iters = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        if i % SYNC_EVERY == SYNC_EVERY - 1 or i == args.steps - 1:
-            solver.synchronize()           # the host runs at most SYNC_EVERY steps ahead of the device
-            tm = solver.get_timings()      # HIP events recorded on the solver's stream around the kernels of this step
-            t_lin += tm["linearize_ms"]; t_qp += tm["qp_ms"]; n_timed += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if persistent:
+        # ONE launch runs the K steps: every instance does plant -> shift/ramp -> linearise -> QP step after step on its own
+        # wavefront (no instance waits for the slowest QP of the batch); u0 and the QP iteration count of every step come back
+        # to pinned host memory inside the timed region
+        n_hist = max(args.steps, args.warmup, 1)
+        u0_hist = solver.alloc_pinned((n_hist, B, 2))
+        it_hist = np.zeros((n_hist, B), dtype=np.int32)
+        solver.step(S_TARGET, model=0, M_sim=M_SUB)        # a first solve: the loop starts from a control
+        if args.warmup:
+            solver.run_steps(S_TARGET, args.warmup, model=0, M_sim=M_SUB, u0_hist=u0_hist[:args.warmup])
+        barrier()
+        t0 = time.perf_counter()
+        solver.run_steps(S_TARGET, args.steps, model=0, M_sim=M_SUB, u0_hist=u0_hist[:args.steps], qp_iter_hist=it_hist[:args.steps])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t_loop = solver.get_timings()["total_ms"]          # HIP events around the launch, on the solver's stream
+        qp_iters_timed = it_hist[:args.steps]
+    else:
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+            if i % SYNC_EVERY == SYNC_EVERY - 1 or i == args.steps - 1:
+                solver.synchronize()           # the host runs at most SYNC_EVERY steps ahead of the device
+                tm = solver.get_timings()      # HIP events recorded on the solver's stream around the kernels of this step
+                t_lin += tm["linearize_ms"]; t_qp += tm["qp_ms"]; n_timed += 1
+        barrier()
+        elapsed = time.perf_counter() - t0
+        qp_iters_timed = None
     # per-step latency of a batch (step + read-back + wait), outside the timed region: 24 synchronous steps
     step_ms = []
+    t_lin_s = t_qp_s = 0.0
     for i in range(24):
         ts = time.perf_counter()
         step(i); solver.synchronize()
         step_ms.append((time.perf_counter() - ts) * 1e3)
-    qp_iters = solver.get_qp_iter()
+        tm = solver.get_timings(); t_lin_s += tm["linearize_ms"] / 24; t_qp_s += tm["qp_ms"] / 24
+    qp_iters = solver.get_qp_iter() if qp_iters_timed is None else qp_iters_timed
     status = solver.get_status()
+    # per-solve latency of ONE instance (B = 1: the real-time controller of mpc_control_node.cpp), rank 0 only: x0 in from the
+    # host, one control step, u0 back on the host, 60 synchronous steps after 10 of warm-up
+    b1_ms = []
+    if rank == 0:
+        one = BatchedOcpSolver(ocp, 1, track.s_ref, track.kappa_ref, device=device)
+        one.set_x0(x0[:1]); one.init_guess()
+        for i in range(70):
+            ts = time.perf_counter()
+            one.sim_advance(model=0, M_sim=M_SUB)
+            one.set_x0(one.get_x0())              # the state crosses the boundary as a host buffer, as in the ROS node
+            one.prepare_step(S_TARGET); one.solve_async(); one.get_u0()
+            if i >= 10:
+                b1_ms.append((time.perf_counter() - ts) * 1e3)
+        one.free()
 
     if dist is not None:
         import torch
@@ -216,11 +253,15 @@ def main():
         value = total_solves / elapsed
         n_ipm = float(np.mean(qp_iters))
         f_lin, f_qp = flops_per_solve(n_ipm)
-        ms_lin, ms_qp = t_lin / max(n_timed, 1), t_qp / max(n_timed, 1)
-        if ms_lin >= ms_qp:
-            kname, kms, kflops = "k_linearize", ms_lin, f_lin * B
+        if persistent:      # the dominant (only) kernel of the timed region: one launch = steps x batch solves
+            ms_lin, ms_qp = t_lin_s, t_qp_s      # per-phase split: from the per-step launches of the latency section below
+            kname, kms, kflops = "k_steps", t_loop, (f_lin + f_qp) * B * args.steps
         else:
-            kname, kms, kflops = "k_qp_wave", ms_qp, f_qp * B
+            ms_lin, ms_qp = t_lin / max(n_timed, 1), t_qp / max(n_timed, 1)
+            if ms_lin >= ms_qp:
+                kname, kms, kflops = "k_linearize", ms_lin, f_lin * B
+            else:
+                kname, kms, kflops = "k_qp_wave", ms_qp, f_qp * B
         achieved = kflops / (kms * 1e-3) / 1e12
         alg_bytes = 8 * (2 * (N_H + 1) * 8 + 2 * N_H * 2 + 8 + 5)          # 6632 B per solve
         # HBM traffic per launch of the dominant kernel: PMC counters (FETCH_SIZE, WRITE_SIZE) cannot be read from
@@ -230,7 +271,7 @@ def main():
             prof = os.path.join(ROOT, "profiles", "r1", "current_summary.json")
             kk = json.load(open(prof))["kernels"]
             key = [n for n in kk if n.startswith(kname.split("<")[0])][0]
-            if B == 1024:
+            if B == 1024 and (not persistent or kk[key].get("steps_per_launch") == args.steps):
                 traffic, traffic_src = kk[key]["hbm_traffic_bytes_per_launch"], "profiles/r1/current_summary.json"
         except Exception:
             pass
@@ -240,11 +281,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: batch={B}/GPU kinematic bicycle fkin6, N=40, dt=0.05, RK4 x M={M_SUB}, "
-                                   f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 read-back to pinned host memory (stream-ordered)",
+                                   f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 read-back to pinned host memory; "
+                                   + ("all steps in one launch, every instance on its own wavefront (ihm2mpc_run_steps)" if persistent else "one launch per phase and step (ihm2mpc_step)"),
                        "batch_per_gpu": B, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards"},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes * B,
+                         "algorithmic_bytes_per_launch": alg_bytes * B * (args.steps if persistent else 1),
+                         "launch": f"{args.steps} control steps x {B} instances in one launch (persistent per-instance loop)" if persistent else "one RTI iteration of the batch",
                          "note": "fp64 VALU/latency-bound path (no MFMA on it): peak = MI355X fp64 vector = fp64 matrix "
                                  "peak; achieved = algorithmic flops (SURVEY.md 8d model) / HIP-event kernel time",
                          "kernel_ms": kms, "linearize_ms": ms_lin, "qp_ms": ms_qp, "n_ipm_mean": n_ipm, "M": M_SUB,
@@ -252,6 +295,7 @@ def main():
                          "hbm_fraction_algorithmic": alg_bytes * value / world / 1e9 / HBM_PEAK_GBS,
                          "hbm_fraction_executed": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
             "latency_ms_p50_batch": float(np.percentile(step_ms, 50)), "latency_ms_p99_batch": float(np.percentile(step_ms, 99)),
+            "latency_ms_p50_single": float(np.percentile(b1_ms, 50)), "latency_ms_p99_single": float(np.percentile(b1_ms, 99)),
             "status_counts": {str(k): int(v) for k, v in enumerate(np.bincount(status_all, minlength=5)) if v},
             "gather_ms": gather_ms,
             "qp_iter_percentiles": {"p50": float(np.percentile(qp_iters, 50)), "p90": float(np.percentile(qp_iters, 90)),

@@ -256,6 +256,46 @@ def run_closed_loop_device(controller: IHM2Controller, simulator: Simulator, x0:
     return ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
 
 
+def run_closed_loop_persistent(controller: IHM2Controller, simulator: Simulator, x0: np.ndarray, n_steps: int, lap_length: float | None = None
+                               ) -> ClosedLoopResult:
+    """Same loop as :func:`run_closed_loop_device` in ONE launch (``ihm2mpc_run_steps``): every car runs its control periods back
+    to back on its own wavefront, the freezing rules (failed solve, NaN plant state, lap done) are applied on the device, and the
+    histories come back once at the end.  For batches that fit the device at once (4 cars per compute unit) and the reference's
+    OCP; otherwise the solver reports it and :func:`run_closed_loop_device` is the loop to use."""
+    B, s = controller.B, controller.solver
+    code = _PLANT_CODE[simulator.variant]
+    x = np.asarray(x0, dtype=np.float64).reshape(B, 8).copy()
+    t0 = time.perf_counter()
+    s.set_active(None)
+    s.set_x0(x); s.prepare_step(controller.s_target); st0 = s.solve(); u_first = s.get_u0()     # control for the initial state
+    h = s.run_steps(controller.s_target, n_steps, model=code, M_sim=simulator.config.num_steps, freeze=True,
+                    lap_stop=np.inf if lap_length is None else lap_length + 1.0, u0_hist=True, x0_hist=True, status_hist=True)
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    us_raw = np.concatenate([u_first[None], h["u0"][:-1]]); sts = np.concatenate([st0[None], h["status"][:-1]])
+    xs = np.concatenate([x[None], h["x0"]])
+    # the bookkeeping of run_closed_loop_device, replayed on the histories (the device applied the same rules)
+    alive = np.ones(B, dtype=bool); finished = np.zeros(B, dtype=bool); lap_time = np.full(B, np.nan)
+    alive_hist, us = [], []
+    n_done = n_steps
+    for i in range(n_steps):
+        alive_hist.append(alive.copy())
+        alive &= np.isin(sts[i], (0, 2))
+        us.append(np.where(alive[:, None], np.nan_to_num(us_raw[i]), 0.0))
+        if not alive.any():
+            n_done = i + 1
+            break
+        moved = np.any(xs[i + 1] != xs[i], axis=1)
+        alive &= moved | ~alive_hist[-1]          # a NaN plant state froze the car where it was
+        if lap_length is not None:
+            done = alive & (xs[i + 1][:, 0] > lap_length + 1.0)
+            lap_time[done] = (i + 1) * controller.dt
+            finished |= done; alive &= ~done
+    controller.last_status = s.get_status()
+    s.set_active(None)
+    return ClosedLoopResult(xs[:n_done + 1], np.array(us), sts[:n_done], alive, finished, lap_time, [wall_ms / max(n_done, 1)] * n_done,
+                            np.array(alive_hist))
+
+
 def closed_loop(track_data: str | MotionPlan, simulator_type=SimModelVariant.KIN6_DYN6, motion_planner_type: type | None = None,
                 motion_tracker_type: type = IHM2Controller, low_level_controller_type: type | None = None,
                 interation_end_callback: Callable | None = None, cleanup_callback: Callable | None = None, *,

@@ -134,6 +134,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     h->B = cfg->batch;
     h->N = cfg->N;
     h->NS = cfg->N + 1;
+    h->n_cu = prop.multiProcessorCount;
     const size_t B = h->B, N = h->N, NS = h->NS;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -173,7 +174,8 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
-                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc};
+                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
+                    h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -788,6 +790,59 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     }
     HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// n_steps control steps of the MiL loop with everything on the device (python/main.py:476-517).  Where the configuration has a
+// persistent instantiation (fkin6 OCP, RTI, all-hard constraint table) this is ONE launch in which every instance runs its
+// steps back to back; otherwise n_steps x ihm2mpc_step.  Same results either way.
+int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target, int32_t n_steps, int32_t freeze, double lap_stop,
+                      double *u0_hist, double *x0_hist, int32_t *status_hist, int32_t *qp_iter_hist)
+{
+    CHECK_H(h);
+    if (ready(h)) return -1;
+    if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
+    if (n_steps < 1) return fail("n_steps must be >= 1");
+    const size_t B = h->B, n = n_steps;
+    if (h->hist_cap < n) {
+        for (void *p : {(void *)h->hist_u0, (void *)h->hist_x0, (void *)h->hist_st, (void *)h->hist_it}) if (p) (void)hipFree(p);
+        h->hist_u0 = h->hist_x0 = nullptr; h->hist_st = h->hist_it = nullptr; h->hist_cap = 0;
+        if (dalloc(&h->hist_u0, n * B * 2) || dalloc(&h->hist_x0, n * B * 8) || dalloc(&h->hist_st, n * B) || dalloc(&h->hist_it, n * B)) return -1;
+        h->hist_cap = n;
+    }
+    if (freeze && !h->active_set) {       // every car starts driving
+        std::vector<int32_t> ones(B, 1);
+        HIP_TRY(hipMemcpyAsync(h->active, ones.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    // The persistent loop pays off while every instance has a wavefront slot of its own (the QP's 40 KB of LDS allow 4 per CU):
+    // a larger batch would run in rounds of whole n_steps-long loops, whereas launches per step backfill the slots of finished
+    // QPs with the next instances.
+    const bool resident = B <= (size_t)4 * h->n_cu;
+    int rc = 1;
+    if (resident) {
+        HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+        HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+        rc = ihm2_launch_steps(h, model, M_sim, s_target, n_steps, freeze ? 1 : 0, lap_stop, h->hist_u0, h->hist_x0, h->hist_st, h->hist_it);
+        if (rc == 0) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+    }
+    if (rc != 0) {
+        if (freeze) return fail("no persistent loop for this configuration (needs the fkin6 OCP in SQP_RTI mode, an all-hard constraint table and a batch of at most %d): call ihm2mpc_step per control period", 4 * h->n_cu);
+        for (size_t i = 0; i < n; i++) {      // launches per step, histories by device-to-device copies in stream order
+            if (ihm2mpc_step(h, model, M_sim, s_target)) return -1;
+            HIP_TRY(hipMemcpyAsync(h->hist_u0 + i * B * 2, h->u0, B * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->hist_x0 + i * B * 8, h->x0, B * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->hist_st + i * B, h->status, B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->hist_it + i * B, h->qp_iter, B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    // histories: stream-ordered copies; pinned destinations (ihm2mpc_host_alloc) do not block the host
+    if (u0_hist) HIP_TRY(hipMemcpyAsync(u0_hist, h->hist_u0, n * B * 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (x0_hist) HIP_TRY(hipMemcpyAsync(x0_hist, h->hist_x0, n * B * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (status_hist) HIP_TRY(hipMemcpyAsync(status_hist, h->hist_st, n * B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (qp_iter_hist) HIP_TRY(hipMemcpyAsync(qp_iter_hist, h->hist_it, n * B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     return 0;
 }
 

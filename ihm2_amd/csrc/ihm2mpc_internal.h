@@ -28,6 +28,7 @@
 struct ihm2mpc_handle {
     ihm2mpc_config cfg;
     int B, N, NS;
+    int n_cu;                      // compute units of the device
     hipStream_t stream;
     hipStream_t stream2;           // plant + reference ramp of ihm2mpc_step run here, beside shift + linearisation
     hipEvent_t ev_fork, ev_join;
@@ -97,6 +98,11 @@ struct ihm2mpc_handle {
     // allocated by the first SQP solve: the iterate the QP was built at, merit weights, per-solve bookkeeping
     double *ls_x, *ls_u, *ls_pi, *ls_lam, *ls_slk, *ls_wpi, *ls_wlam, *ls_alpha;
     int32_t *ls_done, *ls_status, *ls_iter, *ls_qp_acc;
+
+    // ---- history of ihm2mpc_run_steps, grown on demand ----
+    size_t hist_cap;                // steps the buffers hold
+    double *hist_u0, *hist_x0;      // (steps,B,2), (steps,B,8)
+    int32_t *hist_st, *hist_it;     // (steps,B)
 };
 
 // --- launchers (each defined in one .hip file) ---
@@ -106,7 +112,10 @@ void ihm2_launch_wrap_lap(ihm2mpc_handle *h);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last);
-int ihm2_launch_qp(ihm2mpc_handle *h);   // returns non-zero if the problem does not fit the kernel's limits
+int ihm2_launch_qp(ihm2mpc_handle *h);
+// the persistent per-instance loop (kernels_qp.hip); returns 1 if the configuration has no instantiation of it
+int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
+                      double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it);   // returns non-zero if the problem does not fit the kernel's limits
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,
                      const int32_t *active);
 void ihm2_launch_sim_cart(ihm2mpc_handle *h, int model, int M, double dt, int n_steps, double v_dyn, const double *x, const double *u,

@@ -13,59 +13,11 @@
 // (model.hpp: JX_MASK / S_COL_MASK).  Algorithmic traffic per pair: read 10 + 8 doubles, write 88.
 #include "ihm2mpc_internal.h"
 #include "model.hpp"
+#include "device_steps.hpp"
 
 using namespace ihm2;
 
 namespace {
-
-// position of entry (column c, row i) among the structurally non-zero sensitivities (column-major, 52 / 55 entries)
-__host__ __device__ constexpr int s_pos(int mdl, int c, int i)
-{
-    int p = 0;
-    for (int cc = 0; cc < c; cc++)
-        for (int b = 0; b < 8; b++) p += (S_COL_MASK[mdl][cc] >> b) & 1u;
-    for (int b = 0; b < i; b++) p += (S_COL_MASK[mdl][c] >> b) & 1u;
-    return p;
-}
-__host__ __device__ constexpr int s_count(int mdl) { return s_pos(mdl, 10, 0); }
-
-// one RK4 stage of sensitivity column COL:  dX = S + ah*dK_prev ; dK = Jx dX + Ju[:,COL] ; Sacc += wh*dK
-// SL != nullptr: the sub-step's base sensitivities S live in LDS (entry-major, one word per lane: Sl[pos * 64]) instead of
-// registers -- the dynamic model's forward-AD evaluation needs the registers (it spilled 868 B per lane to scratch)
-template <int MODEL, int COL>
-__device__ __forceinline__ void sens_col_stage(const double (&J)[8][10], const double (&S)[8], const double *Sl, double (&Sacc)[8],
-                                               double (&dK)[8], double ah, double wh)
-{
-    constexpr unsigned cm = S_COL_MASK[MODEL ? 1 : 0][COL];
-    double dX[8];
-#pragma unroll
-    for (int l = 0; l < 8; l++)
-        if ((cm >> l) & 1u) dX[l] = fma(ah, dK[l], Sl ? Sl[s_pos(MODEL ? 1 : 0, COL, l) * 64] : S[l]);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        if (!((cm >> i) & 1u)) continue;
-        double acc = 0.0;
-        if (COL >= 8 && ((JU_MASK[MODEL ? 1 : 0][i] >> (COL - 8)) & 1u)) acc = J[i][COL];
-#pragma unroll
-        for (int l = 0; l < 8; l++)
-            if (((JX_MASK[MODEL ? 1 : 0][i] & cm) >> l) & 1u) acc = fma(J[i][l], dX[l], acc);
-        dK[i] = acc;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if ((cm >> i) & 1u) Sacc[i] = fma(wh, dK[i], Sacc[i]);
-}
-
-template <int MODEL, int COL>
-__device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&dst)[8])
-{
-    constexpr unsigned cm = S_COL_MASK[MODEL ? 1 : 0][COL];
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        if ((cm >> i) & 1u) dst[i] = src[i];
-}
-
-#define FOR_ALL_COLS(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9)
 
 template <int MODEL>
 __global__ __launch_bounds__(64) void k_linearize(
@@ -77,77 +29,8 @@ __global__ __launch_bounds__(64) void k_linearize(
     const int b = (int)(t / N);
     const int k = (int)(t % N);
     if (b >= B) return;
-
-    const double *xk = xs + ((size_t)b * (N + 1) + k) * 8;
-    double x[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) x[i] = xk[i];
-    const double u_T = us[((size_t)b * N + k) * 2 + 0];
-    const double u_d = us[((size_t)b * N + k) * 2 + 1];
-    const int tid = track_id[b];
-    TrackSeg trk;
-    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
-
-    // S, Sacc, dK: [column][row]; only rows in S_COL_MASK[column] are ever touched
-    constexpr bool S_IN_LDS = MODEL != IHM2MPC_MODEL_FKIN6;
     extern __shared__ double s_lds[];
-    double *Sl = S_IN_LDS ? s_lds + threadIdx.x : nullptr;
-    double S[10][8], Sacc[10][8], dK[10][8];
-#pragma unroll
-    for (int c = 0; c < 10; c++)
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            S[c][i] = (c == i) ? 1.0 : 0.0; dK[c][i] = 0.0;
-            if (S_IN_LDS) {
-                Sacc[c][i] = S[c][i];
-                if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = S[c][i];
-            }
-        }
-
-    const double h = dt / M;
-    for (int m = 0; m < M; m++) {
-        double xacc[8], K[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
-#define COPY_S_TO_ACC(c) sens_col_copy<MODEL, c>(S[c], Sacc[c]);
-        if (!S_IN_LDS) { FOR_ALL_COLS(COPY_S_TO_ACC) }      // with S in LDS, Sacc already holds S from the previous sub-step
-#pragma unroll 1
-        for (int st = 0; st < 4; st++) {
-            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
-            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
-            double X[8], J[8][10];
-#pragma unroll
-            for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
-            if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, K, J);
-#pragma unroll
-            for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
-#define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sl, Sacc[c], dK[c], ah, wh);
-            FOR_ALL_COLS(STAGE_COL)
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = xacc[i];
-#define COPY_ACC_TO_S(c) sens_col_copy<MODEL, c>(Sacc[c], S[c]);
-        if (!S_IN_LDS) { FOR_ALL_COLS(COPY_ACC_TO_S) }
-        else {
-#pragma unroll
-            for (int c = 0; c < 10; c++)
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = Sacc[c][i];
-        }
-    }
-
-    // output record [A (8x8 row-major) | B (8x2) | b = Phi(x_k,u_k) - x_{k+1}]
-    double *rec = lin + ((size_t)b * N + k) * LIN_REC;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL ? 1 : 0][j] >> i) & 1u) ? (S_IN_LDS ? Sacc[j][i] : S[j][i]) : 0.0;
-#pragma unroll
-        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL ? 1 : 0][8 + j] >> i) & 1u) ? (S_IN_LDS ? Sacc[8 + j][i] : S[8 + j][i]) : 0.0;
-        rec[80 + i] = x[i] - xk[8 + i];
-    }
+    dev_linearize<MODEL>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, MODEL != IHM2MPC_MODEL_FKIN6 ? s_lds + threadIdx.x : nullptr);
 }
 
 // plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 (-2: with fdyn6u) = kin/dyn switch of
@@ -159,47 +42,7 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    if (active && !active[b]) {          // a frozen instance keeps its state (closed loops: failed or finished cars)
-        if (xn != xs) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
-        return;
-    }
-    double x[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) x[i] = xs[(size_t)b * 8 + i];
-    const double u_T = us[(size_t)b * 2], u_d = us[(size_t)b * 2 + 1];
-    const int tid = track_id[b];
-    TrackSeg trk;
-    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
-    int mdl = model;
-    if (model < 0) {
-        const double beta = atan(k_rwd * tan(x[7]));
-        const double v2 = x[3] * x[3] + x[4] * x[4];
-        mdl = (v2 * sin(beta) / k_lR <= 3.0) ? IHM2MPC_MODEL_FKIN6 : (model == -2 ? IHM2MPC_MODEL_FDYN6U : IHM2MPC_MODEL_FDYN6);
-    }
-    const double h = dt / M;
-    double J[8][10];
-    for (int m = 0; m < M; m++) {
-        double xacc[8], K[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
-#pragma unroll 1
-        for (int st = 0; st < 4; st++) {
-            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
-            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
-            double X[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
-            if (mdl == IHM2MPC_MODEL_FKIN6) fkin6_eval<false>(X, u_T, u_d, trk, K, J);
-            else if (mdl == IHM2MPC_MODEL_FDYN6U) fdyn6_eval<false, true>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval<false, false>(X, u_T, u_d, trk, K, J);
-#pragma unroll
-            for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = xacc[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = x[i];
+    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active);
 }
 
 }  // namespace

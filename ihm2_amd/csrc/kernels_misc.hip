@@ -6,59 +6,25 @@
 //    (StanleyController.compute_control, python/main.py:139-163; torque: P-term only).
 #include "ihm2mpc_internal.h"
 #include "model.hpp"
+#include "device_steps.hpp"
 
 using namespace ihm2;
 
 namespace {
 
-// yref_j = [s0 + s_target j/N, 0 x 11], yref_e = [s0 + s_target, 0 x 7];
-// x_j <- x_{j+1}, u_j <- u_{j+1} (j < N-1); x_{N-1} <- x_N; u_{N-1} <- 0   (python/main.py:303-322)
-// One wavefront per instance; the old rows are read into registers before anything is overwritten.
 __global__ __launch_bounds__(64) void k_prepare(int B, int N, double s_target, int mode, const double *__restrict__ x0,
                                                 double *__restrict__ x, double *__restrict__ u,
                                                 double *__restrict__ yref, double *__restrict__ yref_e)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= B) return;
-    double *xb = x + (size_t)b * (N + 1) * 8, *ub = u + (size_t)b * N * 2;
-    if (mode & 1) {
-        const double s0 = x0[(size_t)b * 8];
-        double *yb = yref + (size_t)b * N * 12, *ye = yref_e + (size_t)b * 8;
-        for (int e = lane; e < N * 12; e += 64) yb[e] = (e % 12 == 0) ? s0 + s_target * (e / 12) / N : 0.0;
-        if (lane < 8) ye[lane] = (lane == 0) ? s0 + s_target : 0.0;
-    }
-    if (!(mode & 2)) return;
-    // shift: element e of stage j takes the value of stage j+1 (j < N-1); stage N-1 takes stage N
-    const int nx = N * 8;                    // rows 0..N-1 are rewritten, row N stays
-    for (int base = 0; base < nx; base += 64) {
-        const int e = base + lane;
-        const double v = (e < nx) ? xb[e + 8] : 0.0;
-        __syncthreads();                     // all reads of this chunk (incl. the overlap) before its writes
-        if (e < nx) xb[e] = v;
-        __syncthreads();
-    }
-    const int nu = N * 2;
-    for (int base = 0; base < nu; base += 64) {
-        const int e = base + lane;
-        const double v = (e < nu - 2) ? ub[e + 2] : 0.0;      // u_{N-1} <- 0
-        __syncthreads();
-        if (e < nu) ub[e] = v;
-        __syncthreads();
-    }
+    if ((int)blockIdx.x >= B) return;
+    dev_prepare(blockIdx.x, threadIdx.x, N, s_target, mode, x0, x, u, yref, yref_e);
 }
 
-// Lap wrap for closed loops that run longer than the track tables reach (three laps, s in [-L, 2L)): an instance whose car
-// has passed s = L is moved back by one lap -- x0 and the s-component of its whole iterate -- which changes nothing physically
-// (the tables are periodic) and keeps s inside the table for ever.  L = -s_ref[0] of the instance's track (Track::length).
 __global__ __launch_bounds__(64) void k_wrap_lap(int B, int N, int nknots, const double *__restrict__ s_ref, const int32_t *__restrict__ track_id,
                                                  double *__restrict__ x0, double *__restrict__ x)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= B) return;
-    const double L = -s_ref[(size_t)track_id[b] * nknots];
-    if (!(x0[(size_t)b * 8] >= L)) return;            // wave-uniform
-    for (int k = lane; k <= N; k += 64) x[((size_t)b * (N + 1) + k) * 8] -= L;
-    if (lane == 0) x0[(size_t)b * 8] -= L;
+    if ((int)blockIdx.x >= B) return;
+    dev_wrap_lap(blockIdx.x, threadIdx.x, N, nknots, s_ref, track_id, x0, x);
 }
 
 // MODEL: the model the rollout integrates -- the OCP's own model where that is usable as a simulator (fkin6, fdyn6u), the

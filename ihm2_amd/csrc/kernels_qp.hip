@@ -29,6 +29,9 @@
 //   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands from LDS (row reads broadcast, column reads
 //     consecutive: conflict-free); wave reductions by DPP / permlane butterflies (VALU speed, no LDS crossbar).
 #include "ihm2mpc_internal.h"
+#include "device_steps.hpp"
+
+using namespace ihm2;
 
 namespace {
 
@@ -262,13 +265,13 @@ __device__ __forceinline__ void stream_pairs(const double *linb, double *stage4,
     }
 }
 
+// The QP of instance b, solved by the calling wavefront (all 64 lanes, lane = threadIdx.x); sm: the block's dynamic LDS.
+// Called by k_qp_wave (one launch per RTI iteration) and by the persistent per-instance loop k_steps.
 template <int NSLOT, int NSOFT, int PATH, int UNI>
-__global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
+__device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, double *sm)
 {
-    extern __shared__ double sm[];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int N = a.N, NS = N + 1;
-    if (b >= a.B) return;
     // constraint rows per stage held in LDS: 8 x boxes, 2 u boxes, 2 general rows (+ 2 track rows); the multiplier arrays in
     // HBM always have the full NLAM = 28 columns (14 lower sides, then 14 upper sides)
     constexpr int NCK = PATH ? 14 : 12;
@@ -1005,6 +1008,103 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; }
 }
 
+template <int NSLOT, int NSOFT, int PATH, int UNI>
+__global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
+{
+    extern __shared__ double sm[];
+    if ((int)blockIdx.x >= a.B) return;
+    qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, blockIdx.x, sm);
+}
+
+#if QP_SET == 0
+// ---- persistent per-instance loop: n_steps control steps of the MiL loop (python/main.py:476-517) in ONE launch ----
+// A wavefront owns an instance and runs, step after step,  [lap wrap] -> plant (lane 0) -> reference ramp + warm-start shift
+// -> linearisation (lane k = interval k) -> QP -> history.  Nothing couples two instances, so nothing makes a wave wait for
+// another one: with one launch per phase the whole batch waits, every step, for its slowest QP (17-18 interior-point iterations
+// when the mean is 9); here the fast instances run ahead and the batch time follows the MEAN iteration count.  The phases are
+// the device functions the stand-alone kernels call (device_steps.hpp, qp_wave_body): the results are those of n_steps calls
+// of ihm2mpc_step.
+// The linearisation and the plant are CALLED, not inlined: each gets its own register allocation instead of sharing one with
+// the QP body (inlined, the three together spilled 1.4 KB per lane into the QP's loops); a call per step costs nothing.
+__device__ __noinline__ void call_linearize_fkin6(int b, int k, int N, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
+                                                  const int32_t *track_id, const double *xs, const double *us, double *lin)
+{
+    dev_linearize<IHM2MPC_MODEL_FKIN6>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, nullptr);
+}
+__device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
+                                           const int32_t *track_id, const double *xs, const double *us, double *xn)
+{
+    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
+}
+
+struct StepArgs {
+    int n_steps, model, M_sim, M, nknots, lap_wrap, freeze;
+    double s_target, dt, lap_stop;
+    const double *s_ref, *kappa_ref;
+    double *x0, *yref, *yref_e, *lin;      // the same arrays as QpArgs', writable
+    int32_t *active;                        // (B) or nullptr = all active
+    double *hist_u0, *hist_x0;              // (n_steps,B,2), (n_steps,B,8) or nullptr
+    int32_t *hist_st, *hist_it;             // (n_steps,B) or nullptr
+};
+
+template <int NSLOT, int UNI>
+__global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a)
+{
+    extern __shared__ double sm[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B) return;
+    const int N = a.N;
+    const size_t B = a.B;
+    // a car that stops (freeze) keeps its state: the rest of the history repeats it with zero inputs
+    auto stop_from = [&](int step) {
+        if (s.active && lane == 0) s.active[b] = 0;
+        for (int t = step; t < s.n_steps; t++) {
+            if (s.hist_u0 && lane < 2) s.hist_u0[((size_t)t * B + b) * 2 + lane] = 0.0;
+            if (s.hist_x0 && lane < 8) s.hist_x0[((size_t)t * B + b) * 8 + lane] = s.x0[(size_t)b * 8 + lane];
+            if (s.hist_st && lane == 0) s.hist_st[(size_t)t * B + b] = a.status[b];
+            if (s.hist_it && lane == 0) s.hist_it[(size_t)t * B + b] = 0;
+        }
+    };
+    for (int step = 0; step < s.n_steps; step++) {
+        // wave-uniform: is this car still driving?  (freeze: a failed solve stops it, python/main.py:326-328)
+        bool act = s.active ? s.active[b] != 0 : true;
+        if (s.freeze && act) {
+            const int st = a.status[b];
+            if (st != 0 && st != 2) act = false;
+        }
+        if (!act) { stop_from(step); return; }
+        if (s.lap_wrap) { dev_wrap_lap(b, lane, N, s.nknots, s.s_ref, a.track_id, s.x0, a.x); __syncthreads(); }
+        const double x_old = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
+        if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
+        __syncthreads();
+        if (s.freeze) {     // python/main.py:503-504: a NaN plant state stops the car where it was
+            const double v = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
+            if (__any(v != v)) {
+                if (lane < 8) s.x0[(size_t)b * 8 + lane] = x_old;
+                __syncthreads();
+                stop_from(step);
+                return;
+            }
+        }
+        dev_prepare(b, lane, N, s.s_target, 3, s.x0, a.x, a.u, s.yref, s.yref_e);
+        __syncthreads();
+        for (int k = lane; k < N; k += 64)
+            call_linearize_fkin6(b, k, N, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, a.x, a.u, s.lin);
+        __syncthreads();
+        qp_wave_body<NSLOT, 0, 0, UNI>(a, b, sm);
+        __syncthreads();
+        if (s.hist_u0 && lane < 2) s.hist_u0[((size_t)step * B + b) * 2 + lane] = a.u0[(size_t)b * 2 + lane];
+        if (s.hist_x0 && lane < 8) s.hist_x0[((size_t)step * B + b) * 8 + lane] = s.x0[(size_t)b * 8 + lane];
+        if (s.hist_st && lane == 0) s.hist_st[(size_t)step * B + b] = a.status[b];
+        if (s.hist_it && lane == 0) s.hist_it[(size_t)step * B + b] = a.qp_iter[b];
+        if (s.freeze && s.x0[(size_t)b * 8] > s.lap_stop) {     // python/main.py:514-517: the lap is done
+            if (s.active && lane == 0) s.active[b] = 0;
+            __syncthreads();
+        }
+    }
+}
+#endif
+
 }  // namespace
 
 // This file is compiled TWICE (Makefile): QP_SET = 0 holds the all-hard instantiations (the reference's OCP), built with LLVM's
@@ -1014,7 +1114,59 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 #ifndef QP_SET
 #error "compile with -DQP_SET=0 (all-hard instantiations) or -DQP_SET=1 (soft / track-row instantiations)"
 #endif
+static size_t qp_lds_bytes(const ihm2mpc_handle *h)
+{
+    const size_t N = h->N, NS = h->NS;
+    const int nck = h->path_on ? 14 : 12;
+    const int uni = h->uniform_H && h->uniform_CD;
+    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100 +
+                             (uni ? 20 + (h->path_on ? 0 : 200) : 0));
+}
+
+static QpArgs qp_args(ihm2mpc_handle *h)
+{
+    QpArgs a;
+    a.B = h->B; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max; a.nslots = h->nslot_lane * 64; a.m_act = h->m_act;
+    a.tol = h->cfg.ipm_tol; a.mu0 = h->cfg.ipm_mu0; a.tau0 = h->cfg.ipm_tau0;
+    a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
+    a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
+    a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
+    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
+    a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
+    a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
+    return a;
+}
+
 #if QP_SET == 0
+// n_steps control steps in one launch (k_steps).  Returns 0 launched, 1 the configuration has no persistent instantiation
+// (the caller then runs ihm2mpc_step n_steps times, which gives the same results).
+int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
+                      double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
+{
+    if (h->cfg.model != IHM2MPC_MODEL_FKIN6 || h->cfg.nlp_solver_type != IHM2MPC_SQP_RTI) return 1;
+    if (h->path_on || h->nsoft_lane != 0 || h->nslot_lane > 8) return 1;
+    const size_t lds = qp_lds_bytes(h);
+    if (lds > 160 * 1024) return 1;
+    QpArgs a = qp_args(h);
+    StepArgs s;
+    s.n_steps = n_steps; s.model = model; s.M_sim = M_sim; s.M = h->cfg.M; s.nknots = h->cfg.nknots; s.lap_wrap = h->lap_wrap ? 1 : 0;
+    s.freeze = freeze; s.s_target = s_target; s.dt = h->cfg.dt; s.lap_stop = lap_stop;
+    s.s_ref = h->s_ref; s.kappa_ref = h->kappa_ref;
+    s.x0 = h->x0; s.yref = h->yref; s.yref_e = h->yref_e; s.lin = h->lin;
+    s.active = (freeze || h->active_set) ? h->active : nullptr;
+    s.hist_u0 = hist_u0; s.hist_x0 = hist_x0; s.hist_st = hist_st; s.hist_it = hist_it;
+    const int uni = h->uniform_H && h->uniform_CD;
+#define LAUNCH_STEPS(NS_, UN_)                                                                                                          \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        hipLaunchKernelGGL((k_steps<NS_, UN_>), dim3(h->B), dim3(64), lds, h->stream, s, a);                                            \
+    } while (0)
+    if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 1); else LAUNCH_STEPS(5, 0); }
+    else { if (uni) LAUNCH_STEPS(8, 1); else LAUNCH_STEPS(8, 0); }
+#undef LAUNCH_STEPS
+    return 0;
+}
+
 int ihm2_launch_qp_hard(ihm2mpc_handle *h)
 #else
 int ihm2_launch_qp_hard(ihm2mpc_handle *h);
@@ -1024,21 +1176,10 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
 #if QP_SET == 1
     if (!h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8) return ihm2_launch_qp_hard(h);
 #endif
-    QpArgs a;
-    a.B = h->B; a.N = h->N; a.iter_max = h->cfg.ipm_iter_max; a.nslots = h->nslot_lane * 64; a.m_act = h->m_act;
-    a.tol = h->cfg.ipm_tol; a.mu0 = h->cfg.ipm_mu0; a.tau0 = h->cfg.ipm_tau0;
-    a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
-    a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
-    a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
-    const int N = h->N, NS = h->NS;
-    const int nck = h->path_on ? 14 : 12;
+    QpArgs a = qp_args(h);
     const int uni = h->uniform_H && h->uniform_CD;
-    const size_t lds = sizeof(double) * ((size_t)NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + (size_t)N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100 +
-                                         (uni ? 20 + (h->path_on ? 0 : 200) : 0));
+    const size_t lds = qp_lds_bytes(h);
     if (lds > 160 * 1024) return 1;
-    a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
-    a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
     const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
 #define LAUNCH_QP(NS_, NO_, PT_)                                                                                          \
     do {                                                                                                                  \

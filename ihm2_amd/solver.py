@@ -197,6 +197,31 @@ class BatchedOcpSolver:
         self.solve_async(n_iter)
         return self.get_status()
 
+    def run_steps(self, s_target: float, n_steps: int, model: int = 0, M_sim: int = 25, freeze: bool = False, lap_stop: float = np.inf,
+                  u0_hist=None, x0_hist=None, status_hist=None, qp_iter_hist=None, wait: bool = True):
+        """``n_steps`` control steps (plant + ``compute_control``) in one launch, every instance running ahead on its own
+        wavefront (``ihm2mpc_run_steps``).  Histories are written into the given arrays -- ``(n_steps, B, 2)``, ``(n_steps, B, 8)``,
+        ``(n_steps, B)`` int32 twice -- or, for ``True``, into fresh ones; returns a dict of those that were asked for."""
+        n = int(n_steps)
+        out = {}
+        def buf(v, shape, dtype, name):
+            if v is None or v is False:
+                return None
+            a = np.empty(shape, dtype=dtype) if v is True else v
+            if a.shape != shape or a.dtype != dtype or not a.flags.c_contiguous:
+                raise ValueError(f"{name} must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+            out[name] = a
+            return a
+        u = buf(u0_hist, (n, self.B, NU), np.float64, "u0"); x = buf(x0_hist, (n, self.B, NX), np.float64, "x0")
+        st = buf(status_hist, (n, self.B), np.int32, "status"); it = buf(qp_iter_hist, (n, self.B), np.int32, "qp_iter")
+        _lib.check(self.lib.ihm2mpc_run_steps(
+            self._h, int(model), int(M_sim), float(s_target), n, int(bool(freeze)), float(lap_stop),
+            None if u is None else _ptr(u), None if x is None else _ptr(x),
+            None if st is None else st.ctypes.data_as(_lib.c_int32_p), None if it is None else it.ctypes.data_as(_lib.c_int32_p)))
+        if wait:
+            self.synchronize()
+        return out
+
     def set_sqp_options(self, globalization="MERIT_BACKTRACKING", alpha_min=0.05, alpha_reduction=0.7, eps_sufficient_descent=1e-4,
                         use_sufficient_descent=False, full_step_dual=False, tol=None):
         """Line search and tolerances of the SQP mode (``python/main.py:230-237``); ``tol`` = (stat, eq, ineq, comp) or a scalar."""

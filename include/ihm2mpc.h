@@ -24,6 +24,7 @@
  *   ihm2mpc_get_residuals     <- solver.get_stats("residuals") (acados)
  *   ihm2mpc_sim_step          <- AcadosSimSolver.simulate(x,u)                  python/main.py:476-502; python/sim.py:9-25
  *   ihm2mpc_step              <- one iteration of the MiL loop (plant + compute_control)  python/main.py:476-517
+ *   ihm2mpc_run_steps         <- n iterations of that loop in one launch                  python/main.py:448-517
  *   ihm2mpc_set_soft          <- ocp.constraints.idxsbx/idxsg/idxsh, cost.zl..Zu         old/generate_acaods_interface.py:380-449
  *   ihm2mpc_set_path_constraints <- model.con_h_expr (track rows), constraints.lh/uh     old/generate_acaods_interface.py:191-212,411-449
  *   ihm2mpc_set_track_geometry, ihm2mpc_project <- Track(csv), Track::project + Frenet states
@@ -212,6 +213,19 @@ int ihm2mpc_set_lap_wrap(ihm2mpc_handle *h, int32_t enable);
 int ihm2mpc_host_alloc(uint64_t nbytes, void **p);
 int ihm2mpc_host_free(void *p);
 int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
+
+/* n_steps control steps of the MiL loop (python/main.py:476-517: plant, reference ramp + shift, one RTI iteration) in ONE
+ * launch: every instance runs its steps back to back on its own wavefront, so no instance waits for the slowest QP of the
+ * batch at every step (throughput follows the mean interior-point iteration count instead of the maximum).  Results are
+ * those of n_steps calls of ihm2mpc_step.  The persistent loop exists for the fkin6 OCP in SQP_RTI mode with an all-hard
+ * constraint table (the reference's OCP) and pays off while every instance has a wavefront of its own (batch <= 4 per compute
+ * unit); any other case runs n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
+ * freeze != 0: the rules of the reference's loop per car -- a solve status other than 0 / 2 (python/main.py:326-328) or a NaN
+ * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
+ * ihm2mpc_set_active is updated accordingly.  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant
+ * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block). */
+int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target, int32_t n_steps, int32_t freeze,
+                      double lap_stop, double *u0_hist, double *x0_hist, int32_t *status_hist, int32_t *qp_iter_hist);
 
 /* ---- Cartesian side of the ROS stack ----
  * Plants of the simulation node (src/ihm2/src/sim_node.cpp:197-257), state (X, Y, phi, v_x, v_y, r, T, delta): */

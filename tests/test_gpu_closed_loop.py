@@ -156,3 +156,63 @@ def test_closed_loop_with_the_live_solver_options(track):
     both = rti.alive & sqp.alive
     err = lambda r: np.sqrt(np.mean(r.x[steps // 2:, both, 1] ** 2))        # rms lateral offset over the second half
     assert err(sqp) <= 1.2 * err(rti) + 0.02
+
+
+@pytest.mark.parametrize("plant,n_max,B", [(0, 2.0, 150), (-1, 0.9, 150), (0, 2.0, 1100)])
+def test_persistent_loop_equals_step_by_step(track, plant, n_max, B):
+    """ihm2mpc_run_steps (every instance runs its control steps back to back on its own wavefront, one launch) gives the
+    results of the same number of ihm2mpc_step calls: same device functions, same order per instance.  B = 1100 does not fit
+    the device at once: run_steps then launches per step internally."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    steps = 12
+    x0 = sample_x0(track, B, seed=31)
+    res = []
+    for persistent in (False, True):
+        s = BatchedOcpSolver(make_ocp(n_max=n_max), B, track.s_ref, track.kappa_ref)     # n_max 0.9: the 8-slot table
+        s.set_lap_wrap(True)
+        s.set_x0(x0); s.init_guess()
+        s.step(40.0, model=plant, M_sim=30)                    # a first solve: u0 and status exist
+        if persistent:
+            h = s.run_steps(40.0, steps, model=plant, M_sim=30, u0_hist=True, x0_hist=True, status_hist=True, qp_iter_hist=True)
+        else:
+            h = dict(u0=[], x0=[], status=[], qp_iter=[])
+            for _ in range(steps):
+                s.step(40.0, model=plant, M_sim=30)
+                h["u0"].append(s.get_u0()); h["x0"].append(s.get_x0()); h["status"].append(s.get_status()); h["qp_iter"].append(s.get_qp_iter())
+            h = {k: np.array(v) for k, v in h.items()}
+        res.append((h, s.get_x(), s.get_u(), s.get_multipliers()))
+        s.free()
+    (ha, xa, ua, ma), (hb, xb, ub, mb) = res
+    np.testing.assert_array_equal(ha["status"], hb["status"])
+    np.testing.assert_array_equal(ha["qp_iter"], hb["qp_iter"])
+    np.testing.assert_array_equal(ha["x0"], hb["x0"])
+    np.testing.assert_array_equal(ha["u0"], hb["u0"])
+    np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
+    np.testing.assert_array_equal(ma[0], mb[0]); np.testing.assert_array_equal(ma[1], mb[1])
+    assert (ha["status"] == 0).mean() > (0.9 if plant == 0 else 0.7)      # n_max 0.9 with the dynamic plant: some QPs are infeasible
+
+
+def test_persistent_closed_loop_equals_the_device_loop(track):
+    """run_closed_loop_persistent (freezing rules on the device, one launch) reproduces run_closed_loop_device."""
+    from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop_device, run_closed_loop_persistent
+    from ihm2_amd.controller import IHM2Controller
+
+    B, steps = 40, 30
+    x0 = sample_x0(track, B, seed=17)
+    out = []
+    for runner in (run_closed_loop_device, run_closed_loop_persistent):
+        ctrl = IHM2Controller(track.s_ref, track.kappa_ref, batch_size=B)
+        sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=40), SimModelVariant.KIN6_DYN6)
+        ctrl.warm_start(x0)
+        out.append(runner(ctrl, sim, x0, steps, lap_length=track.lap_length))
+        ctrl.solver.free()
+    d, p = out
+    n = min(d.u.shape[0], p.u.shape[0])
+    assert n >= 10
+    np.testing.assert_array_equal(d.alive_history[:n], p.alive_history[:n])
+    live = d.alive_history[:n]
+    np.testing.assert_array_equal(p.x[:n][live], d.x[:n][live])
+    np.testing.assert_array_equal(p.u[:n][live], d.u[:n][live])
+    np.testing.assert_array_equal(d.alive, p.alive); np.testing.assert_array_equal(d.finished, p.finished)
+    assert (~d.alive).any() and d.alive.any()              # frozen and running cars in the batch
