@@ -44,6 +44,9 @@ int dalloc(T **p, size_t n)
 {
     HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
     HIP_TRY(hipMemset(*p, 0, n * sizeof(T)));
+    // the handle's streams are non-blocking: they do not wait for the null stream the fill runs on, and an upload that
+    // overtakes it would be zeroed afterwards
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -160,7 +163,8 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     for (size_t i = 0; i < NS * NLAM; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
     DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(active, B); DA(u0, B * 2);
-    DA(lin, B * N * LIN_REC); DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, (B * N + 2 * QM_PAD) * 64); DA(scratch, B * 24);
+    DA(lin, (B * N + B) * LIN_REC);      // + one spare record per instance (the kinematic plant's, never read)
+    DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, (B * N + 2 * QM_PAD) * 64); DA(scratch, B * 24);
 #undef DA
     *out = h;
     return 0;

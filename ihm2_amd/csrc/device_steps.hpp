@@ -109,19 +109,18 @@ __device__ __forceinline__ void sens_col_copy(const double (&src)[8], double (&d
 
 // one lane: interval k of instance b.  Sl: this lane's column of the LDS copy of S (dynamic models), nullptr for fkin6
 template <int MODEL>
-__device__ __forceinline__ void dev_linearize(
-    int b, int k, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
-    const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *xs,
-    const double *us, double *lin, double *Sl)
+// xk (8), uk (2): where to integrate from; x_next (8): the state the defect b is taken against; rec: the 88-double record
+// [A | B | b] written at the end; xn_out (8) or nullptr: Phi(x_k, u_k) itself (the kinematic PLANT is this very function on
+// (x0, u0): it then runs in lockstep with the interval lanes of the same wavefront, see k_steps)
+__device__ __forceinline__ void dev_integrate_sens(
+    const double *xk, const double *uk, const double *x_next, int tid, int M, double dt, int nknots, const double *__restrict__ s_ref,
+    const double *__restrict__ kappa_ref, double *rec, double *xn_out, double *Sl)
 {
-
-    const double *xk = xs + ((size_t)b * (N + 1) + k) * 8;
     double x[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) x[i] = xk[i];
-    const double u_T = us[((size_t)b * N + k) * 2 + 0];
-    const double u_d = us[((size_t)b * N + k) * 2 + 1];
-    const int tid = track_id[b];
+    const double u_T = uk[0];
+    const double u_d = uk[1];
     TrackSeg trk;
     trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
 
@@ -174,27 +173,50 @@ __device__ __forceinline__ void dev_linearize(
     }
 
     // output record [A (8x8 row-major) | B (8x2) | b = Phi(x_k,u_k) - x_{k+1}]
-    double *rec = lin + ((size_t)b * N + k) * LIN_REC;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
         for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL ? 1 : 0][j] >> i) & 1u) ? (S_IN_LDS ? Sacc[j][i] : S[j][i]) : 0.0;
 #pragma unroll
         for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL ? 1 : 0][8 + j] >> i) & 1u) ? (S_IN_LDS ? Sacc[8 + j][i] : S[8 + j][i]) : 0.0;
-        rec[80 + i] = x[i] - xk[8 + i];
+        rec[80 + i] = x[i] - x_next[i];
+    }
+    if (xn_out) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) xn_out[i] = x[i];
     }
 }
 
-// plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 (-2: with fdyn6u) = kin/dyn switch of
-// python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic)
+// one lane: interval k of instance b
+template <int MODEL>
+__device__ __forceinline__ void dev_linearize(
+    int b, int k, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
+    const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *xs,
+    const double *us, double *lin, double *Sl)
+{
+    const double *xk = xs + ((size_t)b * (N + 1) + k) * 8;
+    dev_integrate_sens<MODEL>(xk, us + ((size_t)b * N + k) * 2, xk + 8, track_id[b], M, dt, nknots, s_ref, kappa_ref,
+                              lin + ((size_t)b * N + k) * LIN_REC, nullptr, Sl);
+}
+
+// plant / rollout step: x_next = RK4 x M over dt; model -1 (-2: with fdyn6u) = kin/dyn switch of
+// python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic).
+// The plain kinematic plant (model 0, the OCP's own model) is dev_integrate_sens on (x, u): the same arithmetic as a shooting
+// interval, so that the persistent loop can run it on the spare lane of the linearisation for free; its record goes to
+// spare_rec (88 doubles per instance, never read).  The other models integrate without sensitivities.
 // one lane: instance b
 __device__ __forceinline__ void dev_sim_step(int b, int model, int M, double dt, int nknots,
                                              const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                              const int32_t *__restrict__ track_id, const double *xs,
-                                             const double *us, double *xn, const int32_t *active)
+                                             const double *us, double *xn, const int32_t *active, double *spare_rec)
 {
     if (active && !active[b]) {          // a frozen instance keeps its state (closed loops: failed or finished cars)
         if (xn != xs) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
+        return;
+    }
+    if (model == IHM2MPC_MODEL_FKIN6) {
+        dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xs + (size_t)b * 8, us + (size_t)b * 2, xs + (size_t)b * 8, track_id[b], M, dt, nknots, s_ref, kappa_ref,
+                                                spare_rec + (size_t)b * LIN_REC, xn + (size_t)b * 8, nullptr);
         return;
     }
     double x[8];

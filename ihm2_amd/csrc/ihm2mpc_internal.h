@@ -81,7 +81,7 @@ struct ihm2mpc_handle {
     bool lap_wrap;               // prepare_step / step move cars that passed s = L back by one lap first
     double *u0;     // (B,2) first control of the last solve
 
-    double *lin;    // (B,N,88) linearisation records [A | B | b]
+    double *lin;    // (B,N,88) linearisation records [A | B | b], then B spare records (the kinematic plant's by-product)
     // ---- QP workspace in HBM/L2 (everything else of the QP lives in LDS / registers) ----
     double *q_g;    // (B,NS,10) QP gradient
     double *q_P;    // (B,NS,64) Riccati matrices of the current factorisation

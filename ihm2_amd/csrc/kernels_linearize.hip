@@ -38,11 +38,11 @@ __global__ __launch_bounds__(64) void k_linearize(
 __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double dt, int nknots,
                                                  const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                                  const int32_t *__restrict__ track_id, const double *xs,
-                                                 const double *__restrict__ us, double *xn, const int32_t *__restrict__ active)
+                                                 const double *__restrict__ us, double *xn, const int32_t *__restrict__ active, double *spare_rec)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active);
+    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active, spare_rec);
 }
 
 }  // namespace
@@ -66,5 +66,5 @@ void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, c
 {
     const int blocks = (h->B + 63) / 64;
     hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
-                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active);
+                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active, h->lin + (size_t)h->B * h->N * LIN_REC);
 }

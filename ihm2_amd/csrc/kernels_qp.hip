@@ -1024,17 +1024,17 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 // when the mean is 9); here the fast instances run ahead and the batch time follows the MEAN iteration count.  The phases are
 // the device functions the stand-alone kernels call (device_steps.hpp, qp_wave_body): the results are those of n_steps calls
 // of ihm2mpc_step.
-// The linearisation and the plant are CALLED, not inlined: each gets its own register allocation instead of sharing one with
-// the QP body (inlined, the three together spilled 1.4 KB per lane into the QP's loops); a call per step costs nothing.
-__device__ __noinline__ void call_linearize_fkin6(int b, int k, int N, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
-                                                  const int32_t *track_id, const double *xs, const double *us, double *lin)
+// The integrator and the dynamic plants are CALLED, not inlined: each gets its own register allocation instead of sharing one
+// with the QP body (inlined, the three together spilled 1.4 KB per lane into the QP's loops); a call per step costs nothing.
+__device__ __noinline__ void call_integrate_fkin6(const double *xk, const double *uk, const double *x_next, int tid, int M, double dt, int nknots,
+                                                  const double *s_ref, const double *kappa_ref, double *rec, double *xn_out)
 {
-    dev_linearize<IHM2MPC_MODEL_FKIN6>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, nullptr);
+    dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xk, uk, x_next, tid, M, dt, nknots, s_ref, kappa_ref, rec, xn_out, nullptr);
 }
 __device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
-                                           const int32_t *track_id, const double *xs, const double *us, double *xn)
+                                           const int32_t *track_id, const double *xs, const double *us, double *xn, double *spare_rec)
 {
-    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
+    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr, spare_rec);
 }
 
 struct StepArgs {
@@ -1075,7 +1075,26 @@ __global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a)
         if (!act) { stop_from(step); return; }
         if (s.lap_wrap) { dev_wrap_lap(b, lane, N, s.nknots, s.s_ref, a.track_id, s.x0, a.x); __syncthreads(); }
         const double x_old = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
-        if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
+        // The kinematic plant (model 0) is one more "interval" of the linearisation -- lane N integrates (x0, u0) with the
+        // code of the interval lanes, in lockstep with them -- so it costs no time; the dynamic plants take a phase of their own.
+        const bool kin_plant = s.model == IHM2MPC_MODEL_FKIN6;
+        double *spare = s.lin + (size_t)B * N * LIN_REC;
+        if (!kin_plant) {
+            if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0, spare);
+            __syncthreads();
+        }
+        dev_prepare(b, lane, N, s.s_target, 2, s.x0, a.x, a.u, s.yref, s.yref_e);      // warm-start shift
+        __syncthreads();
+        {
+            const int tid = a.track_id[b];
+            for (int k = lane; k < N + (kin_plant ? 1 : 0); k += 64) {
+                const bool plant = k == N;
+                const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
+                const double *uk = plant ? a.u0 + (size_t)b * 2 : a.u + ((size_t)b * N + k) * 2;
+                call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, tid, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref,
+                                     plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC, plant ? s.x0 + (size_t)b * 8 : nullptr);
+            }
+        }
         __syncthreads();
         if (s.freeze) {     // python/main.py:503-504: a NaN plant state stops the car where it was
             const double v = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
@@ -1086,10 +1105,7 @@ __global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a)
                 return;
             }
         }
-        dev_prepare(b, lane, N, s.s_target, 3, s.x0, a.x, a.u, s.yref, s.yref_e);
-        __syncthreads();
-        for (int k = lane; k < N; k += 64)
-            call_linearize_fkin6(b, k, N, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, a.x, a.u, s.lin);
+        dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
         __syncthreads();
         qp_wave_body<NSLOT, 0, 0, UNI>(a, b, sm);
         __syncthreads();

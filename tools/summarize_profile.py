@@ -1,6 +1,6 @@
 """Condenses a rocprofv3 run (gpurun_out/<dir>/{trace,pmc_fetch,pmc_write}) into profiles/<round>/<tag>_*.csv|json.
 
-    python tools/summarize_profile.py gpurun_out/prof_v3 profiles/r1 v3
+    python tools/summarize_profile.py gpurun_out/prof_v3 profiles/r1 v3 [steps_per_launch]
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B
 request for wide coalesced reads (MI355X_MICROARCH.md, HBM section), so the read side is doubled when the
@@ -15,6 +15,7 @@ import shutil
 import sys
 
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+steps_per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else None      # of the persistent loop k_steps (bench.py --steps = --warmup)
 os.makedirs(dst, exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -42,6 +43,9 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
 for name, k in out["kernels"].items():
     if "FETCH_SIZE_KiB_per_launch" in k and "WRITE_SIZE_KiB_per_launch" in k:
         k["hbm_traffic_bytes_per_launch"] = (2 * k["FETCH_SIZE_KiB_per_launch"] + k["WRITE_SIZE_KiB_per_launch"]) * 1024
+for name, k in out["kernels"].items():
+    if name.startswith("k_steps") and steps_per_launch:
+        k["steps_per_launch"] = steps_per_launch
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1, sort_keys=True)
 for name, k in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("pct", 0)):
     print(f"{name:28s} avg {k.get('avg_us', 0):10.1f} us  {k.get('pct', 0):6.2f} %  "
