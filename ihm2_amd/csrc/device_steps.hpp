@@ -113,8 +113,8 @@ template <int MODEL>
 // [A | B | b] written at the end; xn_out (8) or nullptr: Phi(x_k, u_k) itself (the kinematic PLANT is this very function on
 // (x0, u0): it then runs in lockstep with the interval lanes of the same wavefront, see k_steps)
 __device__ __forceinline__ void dev_integrate_sens(
-    const double *xk, const double *uk, const double *x_next, int tid, int M, double dt, int nknots, const double *__restrict__ s_ref,
-    const double *__restrict__ kappa_ref, double *rec, double *xn_out, double *Sl)
+    const double *xk, const double *__restrict__ uk, const double *x_next, int tid, int M, double dt, int nknots, const double *__restrict__ s_ref,
+    const double *__restrict__ kappa_ref, double *__restrict__ rec, double *xn_out, double *__restrict__ Sl)
 {
     double x[8];
 #pragma unroll
@@ -156,7 +156,7 @@ __device__ __forceinline__ void dev_integrate_sens(
             else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, K, J);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
-#define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sl, Sacc[c], dK[c], ah, wh);
+#define STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], S_IN_LDS ? Sl : nullptr, Sacc[c], dK[c], ah, wh);
             FOR_ALL_COLS(STAGE_COL)
         }
 #pragma unroll
@@ -201,22 +201,15 @@ __device__ __forceinline__ void dev_linearize(
 
 // plant / rollout step: x_next = RK4 x M over dt; model -1 (-2: with fdyn6u) = kin/dyn switch of
 // python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic).
-// The plain kinematic plant (model 0, the OCP's own model) is dev_integrate_sens on (x, u): the same arithmetic as a shooting
-// interval, so that the persistent loop can run it on the spare lane of the linearisation for free; its record goes to
-// spare_rec (88 doubles per instance, never read).  The other models integrate without sensitivities.
+// The plain kinematic plant (model 0, the OCP's own model) is NOT handled here but by dev_sim_step_kin below.
 // one lane: instance b
 __device__ __forceinline__ void dev_sim_step(int b, int model, int M, double dt, int nknots,
                                              const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                              const int32_t *__restrict__ track_id, const double *xs,
-                                             const double *us, double *xn, const int32_t *active, double *spare_rec)
+                                             const double *us, double *xn, const int32_t *active)
 {
     if (active && !active[b]) {          // a frozen instance keeps its state (closed loops: failed or finished cars)
         if (xn != xs) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
-        return;
-    }
-    if (model == IHM2MPC_MODEL_FKIN6) {
-        dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xs + (size_t)b * 8, us + (size_t)b * 2, xs + (size_t)b * 8, track_id[b], M, dt, nknots, s_ref, kappa_ref,
-                                                spare_rec + (size_t)b * LIN_REC, xn + (size_t)b * 8, nullptr);
         return;
     }
     double x[8];
@@ -258,5 +251,20 @@ __device__ __forceinline__ void dev_sim_step(int b, int model, int M, double dt,
     for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = x[i];
 }
 
+
+// The plain kinematic plant (model 0) is dev_integrate_sens on (x, u): the same arithmetic as a shooting interval, so that the
+// persistent loop can run it on the spare lane of the linearisation for free (k_steps); its record goes to spare_rec
+// (88 doubles per instance, never read).
+__device__ __forceinline__ void dev_sim_step_kin(int b, int M, double dt, int nknots, const double *__restrict__ s_ref,
+                                                 const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id,
+                                                 const double *xs, const double *us, double *xn, const int32_t *active, double *spare_rec)
+{
+    if (active && !active[b]) {
+        if (xn != xs) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
+        return;
+    }
+    dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xs + (size_t)b * 8, us + (size_t)b * 2, xs + (size_t)b * 8, track_id[b], M, dt, nknots, s_ref, kappa_ref,
+                                            spare_rec + (size_t)b * LIN_REC, xn + (size_t)b * 8, nullptr);
+}
 
 }  // namespace ihm2

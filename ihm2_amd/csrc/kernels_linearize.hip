@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void k_linearize(
     const int k = (int)(t % N);
     if (b >= B) return;
     extern __shared__ double s_lds[];
-    dev_linearize<MODEL>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, MODEL != IHM2MPC_MODEL_FKIN6 ? s_lds + threadIdx.x : nullptr);
+    dev_linearize<MODEL>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, s_lds + threadIdx.x);      // (unused by fkin6)
 }
 
 // plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 (-2: with fdyn6u) = kin/dyn switch of
@@ -38,11 +38,21 @@ __global__ __launch_bounds__(64) void k_linearize(
 __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double dt, int nknots,
                                                  const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                                  const int32_t *__restrict__ track_id, const double *xs,
-                                                 const double *__restrict__ us, double *xn, const int32_t *__restrict__ active, double *spare_rec)
+                                                 const double *__restrict__ us, double *xn, const int32_t *__restrict__ active)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active, spare_rec);
+    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active);
+}
+
+// the plain kinematic plant (model 0): the integrator of the shooting intervals on (x, u), see dev_sim_step_kin
+__global__ __launch_bounds__(64) void k_sim_step_kin(int B, int M, double dt, int nknots, const double *__restrict__ s_ref,
+                                                     const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *xs,
+                                                     const double *__restrict__ us, double *xn, const int32_t *__restrict__ active, double *spare_rec)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    dev_sim_step_kin(b, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active, spare_rec);
 }
 
 }  // namespace
@@ -65,6 +75,10 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)
 {
     const int blocks = (h->B + 63) / 64;
-    hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
-                       h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active, h->lin + (size_t)h->B * h->N * LIN_REC);
+    if (model == IHM2MPC_MODEL_FKIN6)
+        hipLaunchKernelGGL(k_sim_step_kin, dim3(blocks), dim3(64), 0, stream, h->B, M_sim, h->cfg.dt, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id,
+                           x, u, xn, active, h->lin + (size_t)h->B * h->N * LIN_REC);
+    else
+        hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
+                           h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active);
 }

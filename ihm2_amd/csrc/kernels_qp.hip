@@ -1032,9 +1032,9 @@ __device__ __noinline__ void call_integrate_fkin6(const double *xk, const double
     dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xk, uk, x_next, tid, M, dt, nknots, s_ref, kappa_ref, rec, xn_out, nullptr);
 }
 __device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
-                                           const int32_t *track_id, const double *xs, const double *us, double *xn, double *spare_rec)
+                                           const int32_t *track_id, const double *xs, const double *us, double *xn)
 {
-    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr, spare_rec);
+    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
 }
 
 struct StepArgs {
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a)
         const bool kin_plant = s.model == IHM2MPC_MODEL_FKIN6;
         double *spare = s.lin + (size_t)B * N * LIN_REC;
         if (!kin_plant) {
-            if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0, spare);
+            if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
             __syncthreads();
         }
         dev_prepare(b, lane, N, s.s_target, 2, s.x0, a.x, a.u, s.yref, s.yref_e);      // warm-start shift
