@@ -103,8 +103,8 @@ def cpu_baseline(ocp, track, x0_all, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-step-launches", action="store_true",
