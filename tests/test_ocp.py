@@ -140,3 +140,18 @@ def test_controller_options_build_the_expected_ocp(monkeypatch):
     assert d.path_on == 1 and (d.soft_Z[1:40, [1, 3, 12, 13]] >= 0).all() and (d.soft_Z[1:40, [6, 7, 8, 9, 10, 11]] < 0).all()
     with pytest.raises(ValueError):
         Cm.IHM2Controller(s_ref, np.zeros(30), terminal_bounds="nope")
+
+
+def test_sqp_options_follow_the_live_reference_settings():
+    """python/main.py:230-237: "SQP", max_iter 2, "MERIT_BACKTRACKING"; acados' line-search defaults and tolerance names."""
+    import pytest
+    from conftest import make_ocp
+
+    ocp = make_ocp(nlp_solver_type="SQP", nlp_solver_max_iter=2, globalization="MERIT_BACKTRACKING", nlp_solver_tol_eq=1e-8)
+    d = ocp.flatten()
+    assert (d.nlp_solver_type, d.nlp_solver_max_iter, d.globalization) == ("SQP", 2, "MERIT_BACKTRACKING")
+    assert (d.alpha_min, d.alpha_reduction, d.eps_sufficient_descent, d.use_sufficient_descent, d.full_step_dual) == (0.05, 0.7, 1e-4, 0, 0)
+    np.testing.assert_array_equal(d.sqp_tol, [1e-6, 1e-8, 1e-6, 1e-6])          # stat, eq, ineq, comp; unset ones = nlp_tol
+    assert make_ocp().flatten().globalization == "FIXED_STEP"                   # old/generate.py: plain RTI
+    with pytest.raises(ValueError):
+        make_ocp(globalization="FUNNEL").flatten()
