@@ -1,0 +1,97 @@
+"""SURVEY.md section 8c, self-certifying checks (2) and (7): the model Jacobian against a SYMBOLIC derivative of the reference's
+formulas (sympy), and hypothesis-driven properties of the QP solver on random feasible problems."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import oracle as orc
+from test_oracle_qp import NC, NU, NX, NZ, kkt_report, random_qp
+
+
+def _sympy_fkin6():
+    """python/models.py:232-307 written once more, symbolically; kappa(s) = k0 + k1 (s - s0) on the current table segment."""
+    import sympy as sp
+
+    from ihm2_amd import constants as c
+
+    s, n, psi, v_x, v_y, r, T, delta, u_T, u_delta, k0, k1, s0 = sp.symbols("s n psi v_x v_y r T delta u_T u_delta k0 k1 s0", real=True)
+    delta_dot = (u_delta - delta) / c.t_delta
+    T_dot = (u_T - T) / c.t_T
+    F_motor = c.C_m0 * T
+    F_drag = -(c.C_r0 + c.C_r1 * v_x + c.C_r2 * v_x * v_x) * sp.tanh(10 * v_x)           # smooth_sgn, python/utils.py:19-20
+    F_Rx, F_Fx = F_motor / 2 + F_drag, F_motor / 2
+    rw = sp.Rational(1, 2)                                                                  # rear_weight_distribution
+    beta = sp.atan(rw * sp.tan(delta))
+    beta_dot = rw * (1 + sp.tan(delta) ** 2) / (1 + rw ** 2 * sp.tan(delta) ** 2) * delta_dot
+    v_dot = (F_Rx * sp.cos(beta) + F_Fx * sp.cos(delta - beta)) / c.m
+    kap = k0 + k1 * (s - s0)
+    s_dot = (v_x * sp.cos(psi) - v_y * sp.sin(psi)) / (1 + kap * n)
+    v_y_dot = v_dot * sp.sin(beta) + beta_dot * v_x
+    f = sp.Matrix([s_dot, v_x * sp.sin(psi) + v_y * sp.cos(psi), r - kap * s_dot, v_dot * sp.cos(beta) - beta_dot * v_y, v_y_dot,
+                   c.l_R * v_y_dot - beta_dot, T_dot, delta_dot])
+    xs = [s, n, psi, v_x, v_y, r, T, delta, u_T, u_delta]
+    args = xs + [k0, k1, s0]
+    return sp.lambdify(args, f, "numpy"), sp.lambdify(args, f.jacobian(xs), "numpy")
+
+
+def test_fkin6_jacobian_matches_the_symbolic_derivative(track):
+    f_sym, J_sym = _sympy_fkin6()
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for _ in range(200):
+        x = np.array([rng.uniform(0, track.lap_length), rng.uniform(-1, 1), rng.uniform(-0.4, 0.4), rng.uniform(0.5, 25), rng.uniform(-1, 1),
+                      rng.uniform(-1, 1), rng.uniform(-400, 400), rng.uniform(-0.45, 0.45)])
+        u = np.array([rng.uniform(-500, 500), rng.uniform(-0.5, 0.5)])
+        i = np.searchsorted(track.s_ref, x[0], side="right") - 1
+        k1 = (track.kappa_ref[i + 1] - track.kappa_ref[i]) / (track.s_ref[i + 1] - track.s_ref[i])
+        args = list(x) + list(u) + [track.kappa_ref[i], k1, track.s_ref[i]]
+        xdot, J = orc.jac(0, x, u, track.s_ref, track.kappa_ref)
+        fs = np.asarray(f_sym(*args), dtype=float).ravel(); Js = np.asarray(J_sym(*args), dtype=float)
+        assert np.max(np.abs(xdot - fs) / (1 + np.abs(fs))) < 1e-12
+        worst = max(worst, np.max(np.abs(J - Js) / (1 + np.abs(Js))))
+    assert worst < 1e-11
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 2 ** 31 - 1), N=st.integers(2, 7))
+def test_qp_solution_is_feasible_optimal_and_complementary(seed, N):
+    """On random strictly convex stage-wise QPs that are feasible by construction: the four KKT residual groups vanish,
+    multipliers are non-negative, every bound holds, and no feasible trajectory has a lower objective."""
+    rng = np.random.default_rng(seed)
+    qp = random_qp(rng, N)
+    sol = orc.qp_solve(qp["H"], qp["g"], qp["A"], qp["Bm"], qp["b"], qp["dx0"], qp["R"], qp["dl"], qp["du"], iter_max=60, tol=1e-7)
+    assert sol["status"] in (0, 1)          # 1: iteration cap hit within 1e4 x tol (sqrt(eps) is the floor of a slack-eliminated IPM)
+    stat, eq, ineq, comp, lam_min = kkt_report(qp, sol)
+    scale = 1.0 + max(np.abs(qp["g"]).max(), np.abs(sol["lam"]).max())
+    assert stat < 1e-5 * scale and eq < 1e-6 and ineq < 1e-6 and comp < 1e-5 * scale
+    assert lam_min >= -1e-12
+    z = sol["dz"]
+
+    def objective(zz):
+        return sum(0.5 * zz[k] @ qp["H"][k] @ zz[k] + qp["g"][k] @ zz[k] for k in range(N + 1))
+
+    def rollout(U):
+        zz = np.zeros((N + 1, NZ)); zz[0, :NX] = qp["dx0"]
+        for k in range(N):
+            zz[k, NX:] = U[k]
+            zz[k + 1, :NX] = qp["A"][k] @ zz[k, :NX] + qp["Bm"][k] @ zz[k, NX:] + qp["b"][k]
+        return zz
+
+    def feasible(zz):
+        for k in range(N + 1):
+            Rz = qp["R"][k] @ zz[k]
+            if np.any(Rz < qp["dl"][k] - 1e-6) or np.any(Rz > qp["du"][k] + 1e-6):
+                return False
+        return True
+
+    assert feasible(z)
+    f_opt = objective(z)
+    U_opt = z[:N, NX:]
+    n_tested = 0
+    for _ in range(40):           # feasible competitors: perturbations of the optimal inputs that keep every bound
+        zz = rollout(U_opt + rng.normal(size=(N, NU)) * rng.choice([1e-3, 1e-2, 1e-1]))
+        if feasible(zz):
+            n_tested += 1
+            assert objective(zz) >= f_opt - 1e-5 * (1.0 + abs(f_opt))
+    assert n_tested >= 1 or N >= 2
