@@ -299,8 +299,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *Ginv = Kl + N * 16;      // N*4    Guu^-1 (3 used)
     double *Prb = Ginv + N * 4;      // N*8    P_{k+1} rb_k (same for predictor and corrector)
     double *stage2 = Prb + N * 8;    // 2*88   staging slots of the streamed records
-    double *Pn = stage2 + 2 * LIN_REC; // 64   P_{k+1}
-    double *Ws = Pn + 64;            // 80     [l][10]
+    double *Pn = stage2 + 2 * LIN_REC; // 72   P_{k+1}, rows padded to 9: the W phase reads 8 rows at once (stride 8 = 2-way bank conflict)
+    double *Ws = Pn + 72;            // 80     [l][10]
     double *Gs = Ws + 80;            // 100
     double *hc = Gs + 100;           // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
     double *Hl = hc + (PATH ? NS * 2 : 0);   // 200  stage and terminal Hessian (HL only)
@@ -662,7 +662,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                         const double g12 = gam[N * NCK + 12], g13 = gam[N * NCK + 13], a0 = hc[N * 2], a1 = hc[N * 2 + 1];
                         v += (i == 1 && j == 1) ? g12 + g13 : (i == 2 && j == 2) ? g12 * a0 * a0 + g13 * a1 * a1 : g12 * a0 - g13 * a1;
                     }
-                    Pn[lane] = v;
+                    Pn[(lane >> 3) * 9 + (lane & 7)] = v;
                     Pg[(size_t)N * 64 + lane] = v;
                 }
                 // this lane's entry of the stage Hessian / general rows, prefetched one stage ahead
@@ -711,8 +711,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                         double acc = 0.0, acc2 = 0.0;
 #pragma unroll
                         for (int l = 0; l < 8; l++) {
-                            acc = fma(Pn[i * 8 + l], AB[l * 8 + j], acc);
-                            acc2 = fma(Pn[i2 * 8 + l], q[l * qs], acc2);
+                            acc = fma(Pn[i * 9 + l], AB[l * 8 + j], acc);
+                            acc2 = fma(Pn[i2 * 9 + l], q[l * qs], acc2);
                         }
                         Ws[i * 10 + j] = acc;
                         if (lane < 16) Ws[i2 * 10 + 8 + (lane & 1)] = acc2;
@@ -753,7 +753,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                         const double idet = 1.0 / (g00 * g11 - g01 * g01);
                         const double Gi0 = g11 * idet, Gi1 = -g01 * idet, Gi2 = g00 * idet;
                         const double v = gij - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
-                        Pn[lane] = v;
+                        Pn[(lane >> 3) * 9 + (lane & 7)] = v;
                         Pg[(size_t)k * 64 + lane] = v;
                         const double gx0 = (j0 == i) ? ai : cj, gx1 = (j0 == i) ? bi : dj;      // G[j0][8], G[j0][9]
                         const double K0 = Gi0 * gx0 + Gi1 * gx1, K1 = Gi1 * gx0 + Gi2 * gx1;     // K[0][j0], K[1][j0]
@@ -1135,7 +1135,7 @@ static size_t qp_lds_bytes(const ihm2mpc_handle *h)
     const size_t N = h->N, NS = h->NS;
     const int nck = h->path_on ? 14 : 12;
     const int uni = h->uniform_H && h->uniform_CD;
-    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 64 + 80 + 100 +
+    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 72 + 80 + 100 +
                              (uni ? 20 + (h->path_on ? 0 : 200) : 0));
 }
 
