@@ -505,10 +505,26 @@ def test_misuse_of_the_extended_abi_is_reported(track):
         s.sim_step_cart(np.zeros((B, 8)), np.zeros((B, 2)), model=7)
     with pytest.raises(_lib.Ihm2mpcError):
         s.step(40.0, model=9, M_sim=10)
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.run_steps(40.0, 0)                                  # no steps
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.run_steps(40.0, 3, model=5)
+    with pytest.raises(ValueError):
+        s.run_steps(40.0, 3, u0_hist=np.zeros((3, B, 3)))     # history array of the wrong shape
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.set_sqp_options("MERIT_BACKTRACKING", alpha_min=0.0)
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.set_sqp_options("MERIT_BACKTRACKING", alpha_reduction=1.0)
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.set_sqp_options("FIXED_STEP", tol=-1.0)
+    with pytest.raises(_lib.Ihm2mpcError):
+        s.get_sqp_stats()                                     # no SQP-mode solve has run on this (RTI) handle
     # the handle is still usable
     s.set_x0(sample_x0(track, B, seed=3)); s.init_guess()
     s.step(40.0, model=0, M_sim=25)
     assert np.all(s.get_status() == 0)
+    h = s.run_steps(40.0, 3, status_hist=True)
+    assert h["status"].shape == (3, B) and np.all(h["status"] == 0)
     s.free()
 
 
