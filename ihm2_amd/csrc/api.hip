@@ -797,6 +797,22 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     return 0;
 }
 
+// room for the histories of ihm2mpc_run_steps: growing them costs a few device allocations, which a caller that times its
+// run_steps calls wants to have behind it
+int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps)
+{
+    CHECK_H(h);
+    if (n_steps < 1) return fail("n_steps must be >= 1");
+    const size_t B = h->B, n = n_steps;
+    if (h->hist_cap >= n) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (void *p : {(void *)h->hist_u0, (void *)h->hist_x0, (void *)h->hist_st, (void *)h->hist_it}) if (p) (void)hipFree(p);
+    h->hist_u0 = h->hist_x0 = nullptr; h->hist_st = h->hist_it = nullptr; h->hist_cap = 0;
+    if (dalloc(&h->hist_u0, n * B * 2) || dalloc(&h->hist_x0, n * B * 8) || dalloc(&h->hist_st, n * B) || dalloc(&h->hist_it, n * B)) return -1;
+    h->hist_cap = n;
+    return 0;
+}
+
 // n_steps control steps of the MiL loop with everything on the device (python/main.py:476-517).  Where the configuration has a
 // persistent instantiation (fkin6 OCP, RTI, all-hard constraint table) this is ONE launch in which every instance runs its
 // steps back to back; otherwise n_steps x ihm2mpc_step.  Same results either way.
@@ -809,12 +825,7 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     if (n_steps < 1) return fail("n_steps must be >= 1");
     const size_t B = h->B, n = n_steps;
-    if (h->hist_cap < n) {
-        for (void *p : {(void *)h->hist_u0, (void *)h->hist_x0, (void *)h->hist_st, (void *)h->hist_it}) if (p) (void)hipFree(p);
-        h->hist_u0 = h->hist_x0 = nullptr; h->hist_st = h->hist_it = nullptr; h->hist_cap = 0;
-        if (dalloc(&h->hist_u0, n * B * 2) || dalloc(&h->hist_x0, n * B * 8) || dalloc(&h->hist_st, n * B) || dalloc(&h->hist_it, n * B)) return -1;
-        h->hist_cap = n;
-    }
+    if (ihm2mpc_reserve_history(h, n_steps)) return -1;
     if (freeze && !h->active_set) {       // every car starts driving
         std::vector<int32_t> ones(B, 1);
         HIP_TRY(hipMemcpyAsync(h->active, ones.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));

@@ -197,6 +197,10 @@ class BatchedOcpSolver:
         self.solve_async(n_iter)
         return self.get_status()
 
+    def reserve_history(self, n_steps: int):
+        """Device room for the histories of ``run_steps`` calls of up to ``n_steps`` steps."""
+        _lib.check(self.lib.ihm2mpc_reserve_history(self._h, int(n_steps)))
+
     def run_steps(self, s_target: float, n_steps: int, model: int = 0, M_sim: int = 25, freeze: bool = False, lap_stop: float = np.inf,
                   u0_hist=None, x0_hist=None, status_hist=None, qp_iter_hist=None, wait: bool = True):
         """``n_steps`` control steps (plant + ``compute_control``) in one launch, every instance running ahead on its own

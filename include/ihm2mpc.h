@@ -224,6 +224,9 @@ int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
  * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
  * ihm2mpc_set_active is updated accordingly.  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant
  * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block). */
+/* device room for the histories of up to n_steps steps (run_steps grows it on demand; reserving keeps the allocations out of
+ * a timed call) */
+int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps);
 int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target, int32_t n_steps, int32_t freeze,
                       double lap_stop, double *u0_hist, double *x0_hist, int32_t *status_hist, int32_t *qp_iter_hist);
 
