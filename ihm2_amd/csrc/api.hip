@@ -178,7 +178,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
-                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
+                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
@@ -534,7 +534,7 @@ static int sqp_buffers(ihm2mpc_handle *h)
     const size_t B = h->B, N = h->N, NS = h->NS;
 #define DA(p, n) if (dalloc(&h->p, (n))) return -1
     DA(ls_x, B * NS * 8); DA(ls_u, B * N * 2); DA(ls_pi, B * NS * 8); DA(ls_lam, B * NS * NLAM); DA(ls_slk, B * NS * NLAM);
-    DA(ls_wpi, B * NS * 8); DA(ls_wlam, B * NS * NLAM); DA(ls_alpha, B); DA(ls_done, B); DA(ls_status, B); DA(ls_iter, B); DA(ls_qp_acc, B);
+    DA(ls_wpi, B * NS * 8); DA(ls_wlam, B * NS * NLAM); DA(ls_alpha, B); DA(ls_args, 64); DA(ls_done, B); DA(ls_status, B); DA(ls_iter, B); DA(ls_qp_acc, B);
 #undef DA
     return 0;
 }
@@ -836,6 +836,7 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
     // QPs with the next instances.
     const bool resident = B <= (size_t)4 * h->n_cu;
     int rc = 1;
+    if (h->cfg.nlp_solver_type == IHM2MPC_SQP && sqp_buffers(h)) return -1;
     if (resident) {
         HIP_TRY(hipEventRecord(h->ev[0], h->stream));
         HIP_TRY(hipEventRecord(h->ev[1], h->stream));

@@ -30,6 +30,7 @@
 //     consecutive: conflict-free); wave reductions by DPP / permlane butterflies (VALU speed, no LDS crossbar).
 #include "ihm2mpc_internal.h"
 #include "device_steps.hpp"
+#include "sqp_body.hpp"
 
 using namespace ihm2;
 
@@ -1037,8 +1038,14 @@ __device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, i
     dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
 }
 
+__device__ __noinline__ void call_line_search_fkin6(const LsArgs &ls, int b, int it, int last)
+{
+    line_search_body<IHM2MPC_MODEL_FKIN6>(ls, b, it, last);
+}
+
 struct StepArgs {
     int n_steps, model, M_sim, M, nknots, lap_wrap, freeze;
+    int sqp_iters;                          // 0: one RTI iteration per step; > 0: SQP mode, that many iterations with the line search
     double s_target, dt, lap_stop;
     const double *s_ref, *kappa_ref;
     double *x0, *yref, *yref_e, *lin;      // the same arrays as QpArgs', writable
@@ -1047,9 +1054,12 @@ struct StepArgs {
     int32_t *hist_st, *hist_it;             // (n_steps,B) or nullptr
 };
 
-template <int NSLOT, int UNI>
-__global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a)
+// SQP = 0: one RTI iteration per step (the SQP code is compiled out: next to the QP body it changed the register allocation of
+// the whole kernel and tripled the step time); SQP = 1: sqp_iters iterations with the KKT test and the line search.
+template <int NSLOT, int UNI, int SQP>
+__global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a, const LsArgs *lsp)
 {
+    const LsArgs &ls = *lsp;       // in device memory: a by-value kernel argument whose address is taken would be copied to scratch
     extern __shared__ double sm[];
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= a.B) return;
@@ -1084,31 +1094,54 @@ __global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a)
             __syncthreads();
         }
         dev_prepare(b, lane, N, s.s_target, 2, s.x0, a.x, a.u, s.yref, s.yref_e);      // warm-start shift
+        const int n_it = SQP ? s.sqp_iters : 1;
+        if (SQP && lane == 0) { ls.done[b] = 0; ls.sqp_iter[b] = 0; ls.qp_acc[b] = 0; }      // per-solve bookkeeping of the SQP mode
         __syncthreads();
-        {
-            const int tid = a.track_id[b];
-            for (int k = lane; k < N + (kin_plant ? 1 : 0); k += 64) {
-                const bool plant = k == N;
-                const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
-                const double *uk = plant ? a.u0 + (size_t)b * 2 : a.u + ((size_t)b * N + k) * 2;
-                call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, tid, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref,
-                                     plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC, plant ? s.x0 + (size_t)b * 8 : nullptr);
+        for (int it = 0; it < n_it; it++) {
+            if (SQP) {      // the iterate the QP is built at: the line search walks from it towards the QP's full step
+                const int NS = N + 1;
+                for (int e = lane; e < NS * 8; e += 64) {
+                    ((double *)ls.xp)[(size_t)b * NS * 8 + e] = a.x[(size_t)b * NS * 8 + e];
+                    ((double *)ls.pip)[(size_t)b * NS * 8 + e] = a.pi[(size_t)b * NS * 8 + e];
+                }
+                for (int e = lane; e < N * 2; e += 64) ((double *)ls.up)[(size_t)b * N * 2 + e] = a.u[(size_t)b * N * 2 + e];
+                for (int e = lane; e < NS * 28; e += 64) {
+                    ((double *)ls.lamp)[(size_t)b * NS * 28 + e] = a.lam[(size_t)b * NS * 28 + e];
+                    ((double *)ls.slkp)[(size_t)b * NS * 28 + e] = a.slk[(size_t)b * NS * 28 + e];
+                }
             }
-        }
-        __syncthreads();
-        if (s.freeze) {     // python/main.py:503-504: a NaN plant state stops the car where it was
-            const double v = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
-            if (__any(v != v)) {
-                if (lane < 8) s.x0[(size_t)b * 8 + lane] = x_old;
+            {
+                const int tid = a.track_id[b];
+                const bool with_plant = kin_plant && it == 0;
+                for (int k = lane; k < N + (with_plant ? 1 : 0); k += 64) {
+                    const bool plant = k == N;
+                    const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
+                    const double *uk = plant ? a.u0 + (size_t)b * 2 : a.u + ((size_t)b * N + k) * 2;
+                    call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, tid, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref,
+                                         plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC, plant ? s.x0 + (size_t)b * 8 : nullptr);
+                }
+            }
+            __syncthreads();
+            if (it == 0) {
+                if (s.freeze) {     // python/main.py:503-504: a NaN plant state stops the car where it was
+                    const double v = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
+                    if (__any(v != v)) {
+                        if (lane < 8) s.x0[(size_t)b * 8 + lane] = x_old;
+                        __syncthreads();
+                        stop_from(step);
+                        return;
+                    }
+                }
+                dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
                 __syncthreads();
-                stop_from(step);
-                return;
+            }
+            qp_wave_body<NSLOT, 0, 0, UNI>(a, b, sm);
+            __syncthreads();
+            if (SQP) {
+                call_line_search_fkin6(ls, b, it, it == n_it - 1);
+                __syncthreads();
             }
         }
-        dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
-        __syncthreads();
-        qp_wave_body<NSLOT, 0, 0, UNI>(a, b, sm);
-        __syncthreads();
         if (s.hist_u0 && lane < 2) s.hist_u0[((size_t)step * B + b) * 2 + lane] = a.u0[(size_t)b * 2 + lane];
         if (s.hist_x0 && lane < 8) s.hist_x0[((size_t)step * B + b) * 8 + lane] = s.x0[(size_t)b * 8 + lane];
         if (s.hist_st && lane == 0) s.hist_st[(size_t)step * B + b] = a.status[b];
@@ -1159,7 +1192,9 @@ static QpArgs qp_args(ihm2mpc_handle *h)
 int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
                       double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
 {
-    if (h->cfg.model != IHM2MPC_MODEL_FKIN6 || h->cfg.nlp_solver_type != IHM2MPC_SQP_RTI) return 1;
+    if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return 1;
+    const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
+    if (sqp && !h->ls_x) return 1;        // the caller allocates the line-search buffers first
     if (h->path_on || h->nsoft_lane != 0 || h->nslot_lane > 8) return 1;
     const size_t lds = qp_lds_bytes(h);
     if (lds > 160 * 1024) return 1;
@@ -1167,6 +1202,14 @@ int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, 
     StepArgs s;
     s.n_steps = n_steps; s.model = model; s.M_sim = M_sim; s.M = h->cfg.M; s.nknots = h->cfg.nknots; s.lap_wrap = h->lap_wrap ? 1 : 0;
     s.freeze = freeze; s.s_target = s_target; s.dt = h->cfg.dt; s.lap_stop = lap_stop;
+    s.sqp_iters = sqp ? (h->cfg.nlp_solver_max_iter > 0 ? h->cfg.nlp_solver_max_iter : 1) : 0;
+    static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
+    const LsArgs ls_host = make_ls_args(h);
+    if (sqp) {
+        if (hipMemcpyAsync(h->ls_args, &ls_host, sizeof(LsArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+        (void)hipStreamSynchronize(h->stream);      // ls_host leaves scope
+    }
+    const LsArgs *ls = (const LsArgs *)h->ls_args;
     s.s_ref = h->s_ref; s.kappa_ref = h->kappa_ref;
     s.x0 = h->x0; s.yref = h->yref; s.yref_e = h->yref_e; s.lin = h->lin;
     s.active = (freeze || h->active_set) ? h->active : nullptr;
@@ -1174,8 +1217,13 @@ int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, 
     const int uni = h->uniform_H && h->uniform_CD;
 #define LAUNCH_STEPS(NS_, UN_)                                                                                                          \
     do {                                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-        hipLaunchKernelGGL((k_steps<NS_, UN_>), dim3(h->B), dim3(64), lds, h->stream, s, a);                                            \
+        if (sqp) {                                                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipLaunchKernelGGL((k_steps<NS_, UN_, 1>), dim3(h->B), dim3(64), lds, h->stream, s, a, ls);                                 \
+        } else {                                                                                                                        \
+            (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+            hipLaunchKernelGGL((k_steps<NS_, UN_, 0>), dim3(h->B), dim3(64), lds, h->stream, s, a, ls);                                 \
+        }                                                                                                                               \
     } while (0)
     if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 1); else LAUNCH_STEPS(5, 0); }
     else { if (uni) LAUNCH_STEPS(8, 1); else LAUNCH_STEPS(8, 0); }

@@ -158,8 +158,11 @@ def test_closed_loop_with_the_live_solver_options(track):
     assert err(sqp) <= 1.2 * err(rti) + 0.02
 
 
-@pytest.mark.parametrize("plant,n_max,B", [(0, 2.0, 150), (-1, 0.9, 150), (0, 2.0, 1100)])
-def test_persistent_loop_equals_step_by_step(track, plant, n_max, B):
+LIVE = dict(nlp_solver_type="SQP", nlp_solver_max_iter=2, globalization="MERIT_BACKTRACKING")       # python/main.py:230-237
+
+
+@pytest.mark.parametrize("plant,n_max,B,opts", [(0, 2.0, 150, {}), (-1, 0.9, 150, {}), (0, 2.0, 1100, {}), (0, 2.0, 150, LIVE), (-1, 2.0, 70, LIVE)])
+def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts):
     """ihm2mpc_run_steps (every instance runs its control steps back to back on its own wavefront, one launch) gives the
     results of the same number of ihm2mpc_step calls: same device functions, same order per instance.  B = 1100 does not fit
     the device at once: run_steps then launches per step internally."""
@@ -169,7 +172,7 @@ def test_persistent_loop_equals_step_by_step(track, plant, n_max, B):
     x0 = sample_x0(track, B, seed=31)
     res = []
     for persistent in (False, True):
-        s = BatchedOcpSolver(make_ocp(n_max=n_max), B, track.s_ref, track.kappa_ref)     # n_max 0.9: the 8-slot table
+        s = BatchedOcpSolver(make_ocp(n_max=n_max, **opts), B, track.s_ref, track.kappa_ref)     # n_max 0.9: the 8-slot table
         s.set_lap_wrap(True)
         s.set_x0(x0); s.init_guess()
         s.step(40.0, model=plant, M_sim=30)                    # a first solve: u0 and status exist
@@ -181,16 +184,21 @@ def test_persistent_loop_equals_step_by_step(track, plant, n_max, B):
                 s.step(40.0, model=plant, M_sim=30)
                 h["u0"].append(s.get_u0()); h["x0"].append(s.get_x0()); h["status"].append(s.get_status()); h["qp_iter"].append(s.get_qp_iter())
             h = {k: np.array(v) for k, v in h.items()}
-        res.append((h, s.get_x(), s.get_u(), s.get_multipliers()))
+        res.append((h, s.get_x(), s.get_u(), s.get_multipliers(), s.get_sqp_stats() if opts else None))
         s.free()
-    (ha, xa, ua, ma), (hb, xb, ub, mb) = res
+    (ha, xa, ua, ma, sa), (hb, xb, ub, mb, sb) = res
+    if opts:
+        np.testing.assert_array_equal(sa["sqp_iter"], sb["sqp_iter"]); np.testing.assert_array_equal(sa["alpha"], sb["alpha"])
     np.testing.assert_array_equal(ha["status"], hb["status"])
     np.testing.assert_array_equal(ha["qp_iter"], hb["qp_iter"])
     np.testing.assert_array_equal(ha["x0"], hb["x0"])
     np.testing.assert_array_equal(ha["u0"], hb["u0"])
     np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
     np.testing.assert_array_equal(ma[0], mb[0]); np.testing.assert_array_equal(ma[1], mb[1])
-    assert (ha["status"] == 0).mean() > (0.9 if plant == 0 else 0.7)      # n_max 0.9 with the dynamic plant: some QPs are infeasible
+    if opts:        # SQP mode: the step lengths and iteration counts of the last solve agree as well
+        assert np.isin(ha["status"], (0, 2)).mean() > (0.9 if plant == 0 else 0.8)
+    else:
+        assert (ha["status"] == 0).mean() > (0.9 if plant == 0 else 0.7)      # n_max 0.9 with the dynamic plant: some QPs are infeasible
 
 
 def test_persistent_closed_loop_equals_the_device_loop(track):

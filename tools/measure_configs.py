@@ -21,7 +21,7 @@ from ihm2_amd.track import track_table  # noqa: E402
 
 
 def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False, host_state=False,
-                   sqp=None):
+                   sqp=None, persistent=False):
     plans = [track_table(t) for t in tracks]
     mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, {"fkin6": O.fkin6_model, "fdyn6": O.fdyn6_model, "fdyn6u": O.fdyn6u_model}[model], 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
@@ -71,11 +71,18 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
     for _ in range(warmup):
         step()
     solver.synchronize(); t0 = time.perf_counter(); tl = tq = 0.0; n_ok = 0
-    for _ in range(steps):
-        step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]; n_ok += int(np.isin(solver.get_status(), (0, 2) if sqp else (0,)).sum())
+    if persistent:      # all steps in one launch (ihm2mpc_run_steps), histories read back at the end
+        solver.reserve_history(steps)
+        solver.synchronize(); t0 = time.perf_counter()
+        h = solver.run_steps(40.0, steps, model=plant, M_sim=25, u0_hist=True, status_hist=True)
+        n_ok = int(np.isin(h["status"], (0, 2) if sqp else (0,)).sum())
+    else:
+        for _ in range(steps):
+            step(); tm = solver.get_timings(); tl += tm["linearize_ms"]; tq += tm["qp_ms"]; n_ok += int(np.isin(solver.get_status(), (0, 2) if sqp else (0,)).sum())
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
-    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, sqp=sqp, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+    out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, sqp=sqp,
+               persistent=persistent, steps=steps, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
                qp_ms=tq / steps, ok_fraction=n_ok / (B * steps), status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
     if sqp:
@@ -106,6 +113,9 @@ if __name__ == "__main__":
                    (rti_throughput, dict(model="fkin6", B=8192)),
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="FIXED_STEP")),
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING")),
+                   (rti_throughput, dict(model="fkin6", B=1024, persistent=True, steps=500, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="FIXED_STEP", persistent=True, steps=500, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", persistent=True, steps=500, warmup=20)),
                    (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage", track_rows="soft")),
