@@ -153,6 +153,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2);
     DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
     DA(xc, B * 8); DA(s_guess, B);
+    DA(step_args, 32);
     DA(Wd, N * 144 + 64); DA(st_lb, NS * NC); DA(st_ub, NS * NC); DA(st_sz, NS * NLAM); DA(st_sZ, NS * NLAM);
     h->sqp_globalization = 0; h->sqp_use_suff = 0; h->sqp_full_step_dual = 0;
     h->sqp_alpha_min = 0.05; h->sqp_alpha_red = 0.7; h->sqp_eps = 1e-4;
@@ -177,7 +178,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
-                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
+                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
     for (void *p : ptrs) if (p) (void)hipFree(p);

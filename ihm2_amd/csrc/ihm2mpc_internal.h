@@ -98,6 +98,7 @@ struct ihm2mpc_handle {
     // allocated by the first SQP solve: the iterate the QP was built at, merit weights, per-solve bookkeeping
     double *ls_x, *ls_u, *ls_pi, *ls_lam, *ls_slk, *ls_wpi, *ls_wlam, *ls_alpha;
     int32_t *ls_done, *ls_status, *ls_iter, *ls_qp_acc;
+    double *step_args;              // device copy of the persistent loop's own argument block (256 B), allocated with the handle
     double *ls_args;                // device copy of the line search's argument block for the persistent loop (512 B)
 
     // ---- history of ihm2mpc_run_steps, grown on demand ----

@@ -1057,8 +1057,11 @@ struct StepArgs {
 // SQP = 0: one RTI iteration per step (the SQP code is compiled out: next to the QP body it changed the register allocation of
 // the whole kernel and tripled the step time); SQP = 1: sqp_iters iterations with the KKT test and the line search.
 template <int NSLOT, int UNI, int SQP>
-__global__ __launch_bounds__(64) void k_steps(StepArgs s, QpArgs a, const LsArgs *lsp)
+__global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, const LsArgs *lsp)
 {
+    // the loop's own arguments are read from device memory where they are used: as by-value kernel arguments they stayed in
+    // registers across the QP body (50 spill reloads inside its loops that k_qp_wave does not have)
+    const StepArgs &s = *sp;
     const LsArgs &ls = *lsp;       // in device memory: a by-value kernel argument whose address is taken would be copied to scratch
     extern __shared__ double sm[];
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -1214,15 +1217,20 @@ int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, 
     s.x0 = h->x0; s.yref = h->yref; s.yref_e = h->yref_e; s.lin = h->lin;
     s.active = (freeze || h->active_set) ? h->active : nullptr;
     s.hist_u0 = hist_u0; s.hist_x0 = hist_x0; s.hist_st = hist_st; s.hist_it = hist_it;
+    // every field of s is set: upload it
+    static_assert(sizeof(StepArgs) <= 32 * sizeof(double), "step_args holds 256 bytes");
+    if (hipMemcpyAsync(h->step_args, &s, sizeof(StepArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+    (void)hipStreamSynchronize(h->stream);
+    const StepArgs *sdev = (const StepArgs *)h->step_args;
     const int uni = h->uniform_H && h->uniform_CD;
 #define LAUNCH_STEPS(NS_, UN_)                                                                                                          \
     do {                                                                                                                                \
         if (sqp) {                                                                                                                      \
             (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL((k_steps<NS_, UN_, 1>), dim3(h->B), dim3(64), lds, h->stream, s, a, ls);                                 \
+            hipLaunchKernelGGL((k_steps<NS_, UN_, 1>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                                 \
         } else {                                                                                                                        \
             (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL((k_steps<NS_, UN_, 0>), dim3(h->B), dim3(64), lds, h->stream, s, a, ls);                                 \
+            hipLaunchKernelGGL((k_steps<NS_, UN_, 0>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                                 \
         }                                                                                                                               \
     } while (0)
     if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 1); else LAUNCH_STEPS(5, 0); }
