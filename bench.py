@@ -172,7 +172,7 @@ def main():
         u0_hist = solver.alloc_pinned((n_hist, B, 2))
         it_hist = np.zeros((n_hist, B), dtype=np.int32)
         solver.reserve_history(n_hist)
-        solver.run_steps(S_TARGET, 1, model=0, M_sim=M_SUB)   # a first solve (untimed): the loop starts from a control, and the kernel is loaded
+        solver.step(S_TARGET, model=0, M_sim=M_SUB)        # a first solve (untimed, launched per phase): the loop starts from a control
         if args.warmup:
             solver.run_steps(S_TARGET, args.warmup, model=0, M_sim=M_SUB, u0_hist=u0_hist[:args.warmup])
         barrier()
