@@ -224,3 +224,31 @@ def test_persistent_closed_loop_equals_the_device_loop(track):
     np.testing.assert_array_equal(p.u[:n][live], d.u[:n][live])
     np.testing.assert_array_equal(d.alive, p.alive); np.testing.assert_array_equal(d.finished, p.finished)
     assert (~d.alive).any() and d.alive.any()              # frozen and running cars in the batch
+
+
+def test_run_steps_without_waiting_and_in_pieces(track):
+    """Two run_steps calls that do not wait for the device (histories into pinned memory) followed by one synchronize() give what
+    one call over all the steps gives: the loop can be enqueued in pieces while the host does something else."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B, n1, n2 = 96, 5, 7
+    x0 = sample_x0(track, B, seed=41)
+    out = []
+    for pieces in (False, True):
+        s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+        s.set_x0(x0); s.init_guess()
+        s.step(40.0, model=0, M_sim=25)
+        u = s.alloc_pinned((n1 + n2, B, 2))
+        st = np.zeros((n1 + n2, B), dtype=np.int32)
+        if pieces:
+            s.reserve_history(max(n1, n2))
+            s.run_steps(40.0, n1, u0_hist=u[:n1], wait=False)
+            s.run_steps(40.0, n2, u0_hist=u[n1:], wait=False)      # enqueued behind the first piece; its history reuses the device buffers
+            s.synchronize()
+        else:
+            s.run_steps(40.0, n1 + n2, u0_hist=u, status_hist=st)
+            assert np.all(st == 0)
+        out.append((np.array(u), s.get_x(), s.get_u()))
+        s.free()
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
