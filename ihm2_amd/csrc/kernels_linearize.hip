@@ -33,6 +33,93 @@ __global__ __launch_bounds__(64) void k_linearize(
     dev_linearize<MODEL>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, s_lds + threadIdx.x);      // (unused by fkin6)
 }
 
+// The dynamic models keep the integrator in the kernel itself (the code of dev_integrate_sens, written out): as a shared device
+// function the compiler forwarded the LDS-parked base sensitivities through registers (+45 spill stores, +14 %); only the
+// fkin6 integrator is shared with the persistent loop.
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_linearize_dyn(
+    int B, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
+    const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *__restrict__ xs,
+    const double *__restrict__ us, double *__restrict__ lin)
+{
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    const int b = (int)(t / N);
+    const int k = (int)(t % N);
+    if (b >= B) return;
+
+    const double *xk = xs + ((size_t)b * (N + 1) + k) * 8;
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = xk[i];
+    const double u_T = us[((size_t)b * N + k) * 2 + 0];
+    const double u_d = us[((size_t)b * N + k) * 2 + 1];
+    const int tid = track_id[b];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
+
+    // S, Sacc, dK: [column][row]; only rows in S_COL_MASK[column] are ever touched
+    constexpr bool S_IN_LDS = MODEL != IHM2MPC_MODEL_FKIN6;
+    extern __shared__ double s_lds[];
+    double *Sl = S_IN_LDS ? s_lds + threadIdx.x : nullptr;
+    double S[10][8], Sacc[10][8], dK[10][8];
+#pragma unroll
+    for (int c = 0; c < 10; c++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            S[c][i] = (c == i) ? 1.0 : 0.0; dK[c][i] = 0.0;
+            if (S_IN_LDS) {
+                Sacc[c][i] = S[c][i];
+                if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = S[c][i];
+            }
+        }
+
+    const double h = dt / M;
+    for (int m = 0; m < M; m++) {
+        double xacc[8], K[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+#define COPY_S_TO_ACC(c) sens_col_copy<MODEL, c>(S[c], Sacc[c]);
+        if (!S_IN_LDS) { FOR_ALL_COLS(COPY_S_TO_ACC) }      // with S in LDS, Sacc already holds S from the previous sub-step
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+            double X[8], J[8][10];
+#pragma unroll
+            for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+            if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, K, J);
+            else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, K, J);
+#pragma unroll
+            for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+#define DYN_STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sl, Sacc[c], dK[c], ah, wh);
+            FOR_ALL_COLS(DYN_STAGE_COL)
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = xacc[i];
+#define COPY_ACC_TO_S(c) sens_col_copy<MODEL, c>(Sacc[c], S[c]);
+        if (!S_IN_LDS) { FOR_ALL_COLS(COPY_ACC_TO_S) }
+        else {
+#pragma unroll
+            for (int c = 0; c < 10; c++)
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = Sacc[c][i];
+        }
+    }
+
+    // output record [A (8x8 row-major) | B (8x2) | b = Phi(x_k,u_k) - x_{k+1}]
+    double *rec = lin + ((size_t)b * N + k) * LIN_REC;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) rec[i * 8 + j] = ((S_COL_MASK[MODEL ? 1 : 0][j] >> i) & 1u) ? (S_IN_LDS ? Sacc[j][i] : S[j][i]) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) rec[64 + i * 2 + j] = ((S_COL_MASK[MODEL ? 1 : 0][8 + j] >> i) & 1u) ? (S_IN_LDS ? Sacc[8 + j][i] : S[8 + j][i]) : 0.0;
+        rec[80 + i] = x[i] - xk[8 + i];
+    }
+}
+
+
 // plant / rollout step: x_next = RK4 x M over dt, no sensitivities; model -1 (-2: with fdyn6u) = kin/dyn switch of
 // python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic)
 __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double dt, int nknots,
@@ -62,10 +149,10 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
     const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U)
-        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+        hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
-        hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+        hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else
         hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FKIN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
