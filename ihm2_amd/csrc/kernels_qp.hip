@@ -1017,7 +1017,6 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, blockIdx.x, sm);
 }
 
-#if QP_SET == 0
 // ---- persistent per-instance loop: n_steps control steps of the MiL loop (python/main.py:476-517) in ONE launch ----
 // A wavefront owns an instance and runs, step after step,  [lap wrap] -> plant (lane 0) -> reference ramp + warm-start shift
 // -> linearisation (lane k = interval k) -> QP -> history.  Nothing couples two instances, so nothing makes a wave wait for
@@ -1056,7 +1055,7 @@ struct StepArgs {
 
 // SQP = 0: one RTI iteration per step (the SQP code is compiled out: next to the QP body it changed the register allocation of
 // the whole kernel and tripled the step time); SQP = 1: sqp_iters iterations with the KKT test and the line search.
-template <int NSLOT, int UNI, int SQP>
+template <int NSLOT, int NSOFT, int PATH, int UNI, int SQP>
 __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, const LsArgs *lsp)
 {
     // the loop's own arguments are read from device memory where they are used: as by-value kernel arguments they stayed in
@@ -1138,7 +1137,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
                 dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
                 __syncthreads();
             }
-            qp_wave_body<NSLOT, 0, 0, UNI>(a, b, sm);
+            qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm);
             __syncthreads();
             if (SQP) {
                 call_line_search_fkin6(ls, b, it, it == n_it - 1);
@@ -1155,7 +1154,6 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
         }
     }
 }
-#endif
 
 }  // namespace
 
@@ -1189,16 +1187,28 @@ static QpArgs qp_args(ihm2mpc_handle *h)
     return a;
 }
 
-#if QP_SET == 0
 // n_steps control steps in one launch (k_steps).  Returns 0 launched, 1 the configuration has no persistent instantiation
-// (the caller then runs ihm2mpc_step n_steps times, which gives the same results).
+// (the caller then runs ihm2mpc_step n_steps times, which gives the same results).  The all-hard tables are launched from the
+// QP_SET = 0 object, the soft / track-row tables (RTI mode only) from the QP_SET = 1 object.
+#if QP_SET == 0
+int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
+                           double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it);
 int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
                       double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
+#else
+int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
+                           double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
+#endif
 {
     if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return 1;
     const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
     if (sqp && !h->ls_x) return 1;        // the caller allocates the line-search buffers first
-    if (h->path_on || h->nsoft_lane != 0 || h->nslot_lane > 8) return 1;
+    const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8;
+#if QP_SET == 0
+    if (!hard) return ihm2_launch_steps_soft(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
+#else
+    if (hard || sqp) return 1;
+#endif
     const size_t lds = qp_lds_bytes(h);
     if (lds > 160 * 1024) return 1;
     QpArgs a = qp_args(h);
@@ -1206,39 +1216,50 @@ int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, 
     s.n_steps = n_steps; s.model = model; s.M_sim = M_sim; s.M = h->cfg.M; s.nknots = h->cfg.nknots; s.lap_wrap = h->lap_wrap ? 1 : 0;
     s.freeze = freeze; s.s_target = s_target; s.dt = h->cfg.dt; s.lap_stop = lap_stop;
     s.sqp_iters = sqp ? (h->cfg.nlp_solver_max_iter > 0 ? h->cfg.nlp_solver_max_iter : 1) : 0;
-    static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
-    const LsArgs ls_host = make_ls_args(h);
-    if (sqp) {
-        if (hipMemcpyAsync(h->ls_args, &ls_host, sizeof(LsArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
-        (void)hipStreamSynchronize(h->stream);      // ls_host leaves scope
-    }
-    const LsArgs *ls = (const LsArgs *)h->ls_args;
     s.s_ref = h->s_ref; s.kappa_ref = h->kappa_ref;
     s.x0 = h->x0; s.yref = h->yref; s.yref_e = h->yref_e; s.lin = h->lin;
     s.active = (freeze || h->active_set) ? h->active : nullptr;
     s.hist_u0 = hist_u0; s.hist_x0 = hist_x0; s.hist_st = hist_st; s.hist_it = hist_it;
-    // every field of s is set: upload it
+    // every field of s is set: upload it (and the line search's block in the SQP mode)
     static_assert(sizeof(StepArgs) <= 32 * sizeof(double), "step_args holds 256 bytes");
+    static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
+    const LsArgs ls_host = make_ls_args(h);
+    if (sqp && hipMemcpyAsync(h->ls_args, &ls_host, sizeof(LsArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
     if (hipMemcpyAsync(h->step_args, &s, sizeof(StepArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
-    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamSynchronize(h->stream);      // s and ls_host leave scope
     const StepArgs *sdev = (const StepArgs *)h->step_args;
+    const LsArgs *ls = (const LsArgs *)h->ls_args;
     const int uni = h->uniform_H && h->uniform_CD;
-#define LAUNCH_STEPS(NS_, UN_)                                                                                                          \
+#define LAUNCH_STEPS_1(NS_, NO_, PT_, UN_, SQ_)                                                                                         \
     do {                                                                                                                                \
-        if (sqp) {                                                                                                                      \
-            (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL((k_steps<NS_, UN_, 1>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                                 \
-        } else {                                                                                                                        \
-            (void)hipFuncSetAttribute((const void *)k_steps<NS_, UN_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
-            hipLaunchKernelGGL((k_steps<NS_, UN_, 0>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                                 \
-        }                                                                                                                               \
+        (void)hipFuncSetAttribute((const void *)k_steps<NS_, NO_, PT_, UN_, SQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_steps<NS_, NO_, PT_, UN_, SQ_>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                      \
     } while (0)
+#if QP_SET == 0
+#define LAUNCH_STEPS(NS_, UN_) do { if (sqp) LAUNCH_STEPS_1(NS_, 0, 0, UN_, 1); else LAUNCH_STEPS_1(NS_, 0, 0, UN_, 0); } while (0)
     if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 1); else LAUNCH_STEPS(5, 0); }
     else { if (uni) LAUNCH_STEPS(8, 1); else LAUNCH_STEPS(8, 0); }
 #undef LAUNCH_STEPS
+#else
+    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them), RTI mode
+    if (!uni) return 1;
+    const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
+    if (!h->path_on) {
+        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS_1(8, 2, 0, 1, 0);
+        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS_1(10, 4, 0, 1, 0);
+        else return 1;
+    } else {
+        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS_1(8, 2, 1, 1, 0);
+        else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS_1(8, 3, 1, 1, 0);
+        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS_1(10, 4, 1, 1, 0);
+        else return 1;
+    }
+#endif
+#undef LAUNCH_STEPS_1
     return 0;
 }
 
+#if QP_SET == 0
 int ihm2_launch_qp_hard(ihm2mpc_handle *h)
 #else
 int ihm2_launch_qp_hard(ihm2mpc_handle *h);

@@ -217,9 +217,10 @@ int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
 /* n_steps control steps of the MiL loop (python/main.py:476-517: plant, reference ramp + shift, one RTI iteration) in ONE
  * launch: every instance runs its steps back to back on its own wavefront, so no instance waits for the slowest QP of the
  * batch at every step (throughput follows the mean interior-point iteration count instead of the maximum).  Results are
- * those of n_steps calls of ihm2mpc_step.  The persistent loop exists for the fkin6 OCP in SQP_RTI mode with an all-hard
- * constraint table (the reference's OCP) and pays off while every instance has a wavefront of its own (batch <= 4 per compute
- * unit); any other case runs n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
+ * those of n_steps calls of ihm2mpc_step.  The persistent loop exists for the fkin6 OCP -- all-hard constraint tables (the
+ * reference's OCP) in the RTI and the SQP mode, soft / track-row tables with batch-shared weights and rows in the RTI mode --
+ * and pays off while every instance has a wavefront of its own (batch <= 4 per compute unit); any other case runs
+ * n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
  * freeze != 0: the rules of the reference's loop per car -- a solve status other than 0 / 2 (python/main.py:326-328) or a NaN
  * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
  * ihm2mpc_set_active is updated accordingly.  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant

@@ -252,3 +252,50 @@ def test_run_steps_without_waiting_and_in_pieces(track):
         s.free()
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("variant", ["soft_bounds", "soft_track_rows"])
+def test_persistent_loop_with_soft_tables_equals_step_by_step(track, variant):
+    """The persistent loop's instantiations for the soft / track-row constraint tables (old/generate_acaods_interface.py:380-449):
+    bit-identical to launches per step, slacks included."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B, steps = 130, 8
+    x0 = sample_x0(track, B, seed=77)
+    res = []
+    for persistent in (False, True):
+        ocp = make_ocp(n_max=0.6 if variant == "soft_bounds" else 2.0)
+        c = ocp.constraints
+        widths = None
+        if variant == "soft_bounds":
+            c.idxsbx = np.array([0]); c.idxsg = np.array([1])
+            ocp.cost.zl = np.array([50.0, 5.0]); ocp.cost.zu = np.array([50.0, 5.0])
+            ocp.cost.Zl = np.array([200.0, 20.0]); ocp.cost.Zu = np.array([200.0, 20.0])
+        else:
+            ocp.model.con_h_expr = "track"
+            c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+            c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+            ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+            ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+            widths = np.array([[1.2, 1.1]])
+        data = ocp.flatten()
+        s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, track_widths=widths)
+        s.set_soft(data.soft_z, data.soft_Z)
+        s.set_x0(x0); s.init_guess()
+        s.step(40.0, model=0, M_sim=25)
+        if persistent:
+            h = s.run_steps(40.0, steps, model=0, M_sim=25, u0_hist=True, x0_hist=True, status_hist=True, qp_iter_hist=True)
+        else:
+            h = dict(u0=[], x0=[], status=[], qp_iter=[])
+            for _ in range(steps):
+                s.step(40.0, model=0, M_sim=25)
+                h["u0"].append(s.get_u0()); h["x0"].append(s.get_x0()); h["status"].append(s.get_status()); h["qp_iter"].append(s.get_qp_iter())
+            h = {k: np.array(v) for k, v in h.items()}
+        res.append((h, s.get_x(), s.get_u(), s.get_multipliers()[1], s.get_slacks()))
+        s.free()
+    (ha, xa, ua, la, sa), (hb, xb, ub, lb, sb) = res
+    for k in ("status", "qp_iter", "x0", "u0"):
+        np.testing.assert_array_equal(ha[k], hb[k])
+    np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
+    np.testing.assert_array_equal(la, lb); np.testing.assert_array_equal(sa, sb)
+    assert (ha["status"] == 0).mean() > 0.8 and sa.max() > 1e-4          # solved, and slack is really used

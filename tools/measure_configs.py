@@ -117,6 +117,7 @@ if __name__ == "__main__":
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="FIXED_STEP", persistent=True, steps=500, warmup=20)),
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", persistent=True, steps=500, warmup=20)),
                    (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft")),
+                   (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft", persistent=True, steps=500, warmup=20)),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage")),
                    (rti_throughput, dict(model="fdyn6", B=8192, terminal_bounds="stage", track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6", B=8192, track_rows="soft")),
