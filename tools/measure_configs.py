@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 import bench  # noqa: E402
 from ihm2_amd import ocp as O  # noqa: E402
-from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop, run_closed_loop_device  # noqa: E402
+from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop, run_closed_loop_device, run_closed_loop_persistent  # noqa: E402
 from ihm2_amd.controller import IHM2Controller  # noqa: E402
 from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 from ihm2_amd.track import track_table  # noqa: E402
@@ -92,17 +92,18 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
     return out
 
 
-def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="KIN6_DYN6", soft_state_bounds=None, device_loop=False):
+def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="KIN6_DYN6", soft_state_bounds=None, device_loop=False, persistent=False):
     plan = track_table("fsds_competition_1")
     ctrl = IHM2Controller(plan.s_ref, plan.kappa_ref, batch_size=B, terminal_bounds=terminal_bounds, soft_state_bounds=soft_state_bounds)
     sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=100), SimModelVariant[plant])
     x0 = bench.sample_x0(plan, B, seed=5)
     ctrl.warm_start(x0)
     t0 = time.perf_counter()
-    res = (run_closed_loop_device if device_loop else run_closed_loop)(ctrl, sim, x0, steps, lap_length=plan.lap_length)
+    runner = run_closed_loop_persistent if persistent else (run_closed_loop_device if device_loop else run_closed_loop)
+    res = runner(ctrl, sim, x0, steps, lap_length=plan.lap_length)
     el = time.perf_counter() - t0
     st = res.stats()
-    return dict(config=5, terminal_bounds=terminal_bounds, plant=plant, soft_state_bounds=soft_state_bounds, device_loop=device_loop, B=B, steps=int(res.u.shape[0]), wall_s=el, control_steps_per_s=B * res.u.shape[0] / el, alive=int(res.alive.sum()),
+    return dict(config=5, terminal_bounds=terminal_bounds, plant=plant, soft_state_bounds=soft_state_bounds, device_loop=device_loop, persistent=persistent, B=B, steps=int(res.u.shape[0]), wall_s=el, control_steps_per_s=B * res.u.shape[0] / el, alive=int(res.alive.sum()),
                 finished=int(res.finished.sum()), failed=st["failed"], mean_speed=st["mean_speed"],
                 progress_m_median=float(np.median(res.x[-1, :, 0] - res.x[0, :, 0])))
 
@@ -131,5 +132,8 @@ if __name__ == "__main__":
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0))),
                    (closed_loop_config5, dict(B=4096, steps=200, device_loop=True)),
-                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), device_loop=True))):
+                   (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), device_loop=True)),
+                   # the per-GPU share of configs[4] on 8 GPUs: 512 cars
+                   (closed_loop_config5, dict(B=512, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), device_loop=True)),
+                   (closed_loop_config5, dict(B=512, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), persistent=True))):
         print(json.dumps(fn(**kw)), flush=True)
