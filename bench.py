@@ -215,8 +215,8 @@ def main():
         for i in range(70):
             ts = time.perf_counter()
             one.sim_advance(model=0, M_sim=M_SUB)
-            one.set_x0(one.get_x0())              # the state crosses the boundary as a host buffer, as in the ROS node
-            one.prepare_step(S_TARGET); one.solve_async(); one.get_u0()
+            # the state crosses the boundary as a host buffer, as in the ROS node: x0 in, u0 out, one call (ihm2mpc_compute_control)
+            one.compute_control(one.get_x0(), S_TARGET)
             if i >= 10:
                 b1_ms.append((time.perf_counter() - ts) * 1e3)
         one.free()

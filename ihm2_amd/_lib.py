@@ -54,6 +54,7 @@ SYMBOLS = {
     "ihm2mpc_reinit_failed": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_prepare_step": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_solve": (C.c_int, [_H, C.c_int32]),
+    "ihm2mpc_compute_control": (C.c_int, [_H, c_double_p, C.c_double, c_double_p, c_int32_p]),
     "ihm2mpc_reserve_history": (C.c_int, [_H, C.c_int32]),
     "ihm2mpc_run_steps": (C.c_int, [_H, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double, c_double_p, c_double_p, c_int32_p, c_int32_p]),
     "ihm2mpc_set_sqp_options": (C.c_int, [_H, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, c_double_p]),

@@ -194,10 +194,8 @@ class IHM2Controller(Controller):
         for a batch the failed rows are NaN and ``last_status`` holds the codes."""
         x = np.asarray(x, dtype=np.float64)
         single = x.ndim == 1
-        self.solver.set_x0(x.reshape(self.B, NX))          # solver.set(0, "lbx"/"ubx", x)
-        self.solver.prepare_step(self.s_target)            # yref ramp + warm-start shift, on device
-        self.last_status = self.solver.solve()
-        u0 = self.solver.get_u0()
+        # solver.set(0, "lbx"/"ubx", x), yref ramp + warm-start shift (on device), solve, solver.get(0, "u"): one call, one wait
+        u0, self.last_status = self.solver.compute_control(x.reshape(self.B, NX), self.s_target)
         if self.recover_failed:
             # not in the reference (its loop stops at the first bad status, python/main.py:326-328): give the failed instances a
             # fresh rollout as the next warm start instead of the iterate that made their QP infeasible

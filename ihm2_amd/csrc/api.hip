@@ -743,6 +743,24 @@ int ihm2mpc_host_free(void *p)
     return 0;
 }
 
+// IHM2Controller.compute_control (python/main.py:297-334) in one call: x0 in, reference ramp + warm-start shift, one solve
+// (RTI or the configured SQP iterations), u0 and status out -- one host-device round trip, one wait.
+int ihm2mpc_compute_control(ihm2mpc_handle *h, const double *x0, double s_target, double *u0, int32_t *status)
+{
+    CHECK_H(h);
+    if (!x0 || !u0) return fail("null argument");
+    if (ready(h)) return -1;
+    const size_t B = h->B;
+    HIP_TRY(hipMemcpyAsync(h->x0, x0, B * NX * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h->lap_wrap) ihm2_launch_wrap_lap(h);
+    ihm2_launch_prepare(h, s_target, 3, h->stream);
+    if (ihm2mpc_solve(h, 0)) return -1;
+    HIP_TRY(hipMemcpyAsync(u0, h->u0, B * NU * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, h->status, B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst)
 {
     CHECK_H(h);

@@ -33,6 +33,74 @@ __global__ __launch_bounds__(64) void k_linearize(
     dev_linearize<MODEL>(b, k, N, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, lin, s_lds + threadIdx.x);      // (unused by fkin6)
 }
 
+// ---- small batches (the single real-time controller, B = 1): one sensitivity COLUMN per lane ----
+// With few instances the device is empty and the latency of a solve is what counts.  Here wave c of an interval block
+// propagates only column c of S (10 waves per 64 intervals); every lane re-evaluates the model and its Jacobian (10x redundant,
+// on otherwise idle SIMDs) but carries 8 instead of 52 sensitivity entries: 0.11 ms instead of 0.25 ms per linearisation.
+// The formulas per column are those of dev_integrate_sens, but the compiler shares different subexpressions when only one
+// column is needed, so the records agree with k_linearize's to rounding (1e-15 relative), not bit for bit; it is therefore used
+// for up to 128 intervals only (B <= 3 at N = 40), where nothing is compared bit-wise with the batch path.
+template <int COL>
+__device__ __forceinline__ void dev_integrate_col_fkin6(const double *xk, const double *uk, int tid, int M, double dt, int nknots,
+                                                       const double *__restrict__ s_ref, const double *__restrict__ kappa_ref, double *rec)
+{
+    constexpr int MODEL = IHM2MPC_MODEL_FKIN6;
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = xk[i];
+    const double u_T = uk[0], u_d = uk[1];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
+    double S[8], Sacc[8], dK[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { S[i] = (COL == i) ? 1.0 : 0.0; dK[i] = 0.0; Sacc[i] = 0.0; }
+    const double h = dt / M;
+    for (int m = 0; m < M; m++) {
+        double xacc[8], K[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+        sens_col_copy<MODEL, COL>(S, Sacc);
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+            double X[8], J[8][10];
+#pragma unroll
+            for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+            fkin6_eval<true>(X, u_T, u_d, trk, K, J);
+#pragma unroll
+            for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+            sens_col_stage<MODEL, COL>(J, S, nullptr, Sacc, dK, ah, wh);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = xacc[i];
+        sens_col_copy<MODEL, COL>(Sacc, S);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double v = ((S_COL_MASK[0][COL] >> i) & 1u) ? S[i] : 0.0;
+        if (COL < 8) rec[i * 8 + COL] = v; else rec[64 + i * 2 + (COL - 8)] = v;
+        if (COL == 0) rec[80 + i] = x[i] - xk[8 + i];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_linearize_cols(int B, int N, int M, double dt, int nknots, const double *__restrict__ s_ref,
+                                                       const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id,
+                                                       const double *__restrict__ xs, const double *__restrict__ us, double *__restrict__ lin)
+{
+    const long t = (long)blockIdx.x * 64 + threadIdx.x;
+    const int b = (int)(t / N), k = (int)(t % N);
+    if (b >= B) return;
+    const double *xk = xs + ((size_t)b * (N + 1) + k) * 8, *uk = us + ((size_t)b * N + k) * 2;
+    double *rec = lin + ((size_t)b * N + k) * LIN_REC;
+    const int tid = track_id[b];
+    switch (blockIdx.y) {       // block-uniform: one column per wavefront
+#define COL_CASE(c) case c: dev_integrate_col_fkin6<c>(xk, uk, tid, M, dt, nknots, s_ref, kappa_ref, rec); break;
+    FOR_ALL_COLS(COL_CASE)
+#undef COL_CASE
+    }
+}
+
 // The dynamic models keep the integrator in the kernel itself (the code of dev_integrate_sens, written out): as a shared device
 // function the compiler forwarded the LDS-parked base sensitivities through registers (+45 spill stores, +14 %); only the
 // fkin6 integrator is shared with the persistent loop.
@@ -153,6 +221,9 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
         hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+                           h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
+    else if (blocks <= 2)      // one or a few real-time controllers: the latency path (not bit-identical to the batch kernel, see above)
+        hipLaunchKernelGGL(k_linearize_cols, dim3(blocks, 10), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else
         hipLaunchKernelGGL(k_linearize<IHM2MPC_MODEL_FKIN6>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,

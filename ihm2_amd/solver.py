@@ -197,6 +197,13 @@ class BatchedOcpSolver:
         self.solve_async(n_iter)
         return self.get_status()
 
+    def compute_control(self, x0, s_target: float):
+        """``IHM2Controller.compute_control`` (``python/main.py:297-334``) for the whole batch in one call: returns ``(u0, status)``."""
+        u0 = np.empty((self.B, NU)); st = np.empty(self.B, dtype=np.int32)
+        _lib.check(self.lib.ihm2mpc_compute_control(self._h, _ptr(_f64(x0, (self.B, NX), "x0")), float(s_target), _ptr(u0),
+                                                    st.ctypes.data_as(_lib.c_int32_p)))
+        return u0, st
+
     def reserve_history(self, n_steps: int):
         """Device room for the histories of ``run_steps`` calls of up to ``n_steps`` steps."""
         _lib.check(self.lib.ihm2mpc_reserve_history(self._h, int(n_steps)))

@@ -23,6 +23,7 @@
  *   ihm2mpc_get_status        <- return value of solve()                        python/main.py:325-328; dpc/main.py:287-293
  *   ihm2mpc_get_residuals     <- solver.get_stats("residuals") (acados)
  *   ihm2mpc_sim_step          <- AcadosSimSolver.simulate(x,u)                  python/main.py:476-502; python/sim.py:9-25
+ *   ihm2mpc_compute_control   <- IHM2Controller.compute_control(x) as one call            python/main.py:297-334
  *   ihm2mpc_step              <- one iteration of the MiL loop (plant + compute_control)  python/main.py:476-517
  *   ihm2mpc_run_steps         <- n iterations of that loop in one launch                  python/main.py:448-517
  *   ihm2mpc_set_soft          <- ocp.constraints.idxsbx/idxsg/idxsh, cost.zl..Zu         old/generate_acaods_interface.py:380-449
@@ -225,6 +226,10 @@ int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
  * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
  * ihm2mpc_set_active is updated accordingly.  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant
  * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block). */
+/* IHM2Controller.compute_control (python/main.py:297-334) in ONE call for the whole batch: x0 (B,8) in, reference ramp +
+ * warm-start shift + solve (one RTI iteration, or the configured SQP iterations), u0 (B,2) and status (B, may be NULL) out;
+ * one host-device round trip and one wait -- the call of a real-time controller (mpc_control_node.cpp:105-255). */
+int ihm2mpc_compute_control(ihm2mpc_handle *h, const double *x0, double s_target, double *u0, int32_t *status);
 /* device room for the histories of up to n_steps steps (run_steps grows it on demand; reserving keeps the allocations out of
  * a timed call) */
 int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps);

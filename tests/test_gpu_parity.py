@@ -595,3 +595,49 @@ def test_several_tracks_in_one_batch_match_oracle():
     xo = P.sim_step(x0, u[:, 0].copy(), 0, 25, track_id=tid)
     assert _rel(xn, xo) < 1e-11
     s.free()
+
+
+def test_small_batch_linearisation_matches_the_batch_kernel(track):
+    """One to three instances are linearised one sensitivity column per wavefront (the latency path of the single real-time
+    controller); the records are those of the batch kernel to rounding."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    Bs, Bl = 3, 200                       # 3 x 40 intervals: column kernel; 200: batch kernel
+    x0 = sample_x0(track, Bl, seed=55)
+    big = BatchedOcpSolver(make_ocp(), Bl, track.s_ref, track.kappa_ref)
+    big.set_x0(x0); big.init_guess(); big.linearize()
+    A, Bm, b = big.get_linearization()
+    x, u = big.get_x(), big.get_u()
+    small = BatchedOcpSolver(make_ocp(), Bs, track.s_ref, track.kappa_ref)
+    small.set_x0(x0[:Bs]); small.set_x(x[:Bs]); small.set_u(u[:Bs]); small.linearize()
+    As, Bms, bs = small.get_linearization()
+    colscale = np.maximum(np.abs(A[:Bs]).max(axis=2, keepdims=True), 1e-30)
+    assert np.max(np.abs(As - A[:Bs]) / colscale) < 1e-13          # tolerance: 1e-13 column-relative
+    assert np.max(np.abs(Bms - Bm[:Bs]) / np.maximum(np.abs(Bm[:Bs]).max(axis=2, keepdims=True), 1e-30)) < 1e-13
+    assert np.max(np.abs(bs - b[:Bs])) < 1e-13
+    assert np.all(As[:, :, 3:, :3] == 0) and np.all(As[:, :, 6:, :6] == 0)      # structural zeros stay exact
+    big.free(); small.free()
+
+
+def test_compute_control_equals_the_four_calls(track):
+    """ihm2mpc_compute_control = set_x0 + prepare_step + solve + get_u0 (python/main.py:297-334), bit for bit."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = 70
+    x0 = sample_x0(track, B, seed=12)
+    res = []
+    for fused in (False, True):
+        s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+        s.set_x0(x0); s.init_guess()
+        xc = x0.copy()
+        for _ in range(3):
+            xc = s.sim_step(xc, s.get_u0(), model=0, M_sim=25)
+            if fused:
+                u0, st = s.compute_control(xc, 40.0)
+            else:
+                s.set_x0(xc); s.prepare_step(40.0); st = s.solve(); u0 = s.get_u0()
+        res.append((u0, st, s.get_x(), s.get_u(), s.get_multipliers()[1]))
+        s.free()
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+    assert (res[0][1] == 0).sum() >= 0.9 * B
