@@ -50,6 +50,7 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
         sel = tid == t
         x0[sel] = bench.sample_x0(p, int(sel.sum()), seed=20240607 + t)
     solver.set_x0(x0); solver.init_guess()
+    solver.set_lap_wrap(True)        # long runs: cars that complete a lap are moved back by one lap length (the tables hold three laps)
     if model != "fkin6":          # a few SQP iterations on the frozen problem: the kinematic rollout is not a dynamic trajectory
         yref = np.zeros((B, 40, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(40)[None] / 40
         yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
