@@ -1189,7 +1189,7 @@ static QpArgs qp_args(ihm2mpc_handle *h)
 
 // n_steps control steps in one launch (k_steps).  Returns 0 launched, 1 the configuration has no persistent instantiation
 // (the caller then runs ihm2mpc_step n_steps times, which gives the same results).  The all-hard tables are launched from the
-// QP_SET = 0 object, the soft / track-row tables (RTI mode only) from the QP_SET = 1 object.
+// QP_SET = 0 object, the soft / track-row tables from the QP_SET = 1 object.
 #if QP_SET == 0
 int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
                            double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it);
@@ -1207,7 +1207,7 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
 #if QP_SET == 0
     if (!hard) return ihm2_launch_steps_soft(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
 #else
-    if (hard || sqp) return 1;
+    if (hard) return 1;
 #endif
     const size_t lds = qp_lds_bytes(h);
     if (lds > 160 * 1024) return 1;
@@ -1241,19 +1241,21 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     else { if (uni) LAUNCH_STEPS(8, 1); else LAUNCH_STEPS(8, 0); }
 #undef LAUNCH_STEPS
 #else
-    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them), RTI mode
+    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them)
     if (!uni) return 1;
     const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
+#define LAUNCH_STEPS(NS_, NO_, PT_) do { if (sqp) LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 1); else LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 0); } while (0)
     if (!h->path_on) {
-        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS_1(8, 2, 0, 1, 0);
-        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS_1(10, 4, 0, 1, 0);
+        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 0);
+        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0);
         else return 1;
     } else {
-        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS_1(8, 2, 1, 1, 0);
-        else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS_1(8, 3, 1, 1, 0);
-        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS_1(10, 4, 1, 1, 0);
+        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 1);
+        else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS(8, 3, 1);
+        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 1);
         else return 1;
     }
+#undef LAUNCH_STEPS
 #endif
 #undef LAUNCH_STEPS_1
     return 0;

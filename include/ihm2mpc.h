@@ -219,7 +219,7 @@ int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
  * launch: every instance runs its steps back to back on its own wavefront, so no instance waits for the slowest QP of the
  * batch at every step (throughput follows the mean interior-point iteration count instead of the maximum).  Results are
  * those of n_steps calls of ihm2mpc_step.  The persistent loop exists for the fkin6 OCP -- all-hard constraint tables (the
- * reference's OCP) in the RTI and the SQP mode, soft / track-row tables with batch-shared weights and rows in the RTI mode --
+ * reference's OCP) and soft / track-row tables with batch-shared weights and rows, in the RTI and the SQP mode --
  * and pays off while every instance has a wavefront of its own (batch <= 4 per compute unit); any other case runs
  * n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
  * freeze != 0: the rules of the reference's loop per car -- a solve status other than 0 / 2 (python/main.py:326-328) or a NaN

@@ -254,8 +254,8 @@ def test_run_steps_without_waiting_and_in_pieces(track):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("variant", ["soft_bounds", "soft_track_rows"])
-def test_persistent_loop_with_soft_tables_equals_step_by_step(track, variant):
+@pytest.mark.parametrize("variant,opts", [("soft_bounds", {}), ("soft_track_rows", {}), ("soft_track_rows", LIVE)])
+def test_persistent_loop_with_soft_tables_equals_step_by_step(track, variant, opts):
     """The persistent loop's instantiations for the soft / track-row constraint tables (old/generate_acaods_interface.py:380-449):
     bit-identical to launches per step, slacks included."""
     from ihm2_amd.solver import BatchedOcpSolver
@@ -264,7 +264,7 @@ def test_persistent_loop_with_soft_tables_equals_step_by_step(track, variant):
     x0 = sample_x0(track, B, seed=77)
     res = []
     for persistent in (False, True):
-        ocp = make_ocp(n_max=0.6 if variant == "soft_bounds" else 2.0)
+        ocp = make_ocp(n_max=0.6 if variant == "soft_bounds" else 2.0, **opts)
         c = ocp.constraints
         widths = None
         if variant == "soft_bounds":
@@ -298,4 +298,4 @@ def test_persistent_loop_with_soft_tables_equals_step_by_step(track, variant):
         np.testing.assert_array_equal(ha[k], hb[k])
     np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
     np.testing.assert_array_equal(la, lb); np.testing.assert_array_equal(sa, sb)
-    assert (ha["status"] == 0).mean() > 0.8 and sa.max() > 1e-4          # solved, and slack is really used
+    assert np.isin(ha["status"], (0, 2) if opts else (0,)).mean() > 0.8 and sa.max() > 1e-4          # solved, and slack is really used
