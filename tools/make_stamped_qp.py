@@ -16,7 +16,7 @@ s = re.sub(r"/\*@S:(\d+)\*/", lambda m: "STAMP(%s);" % m.group(1), s)
 s = s.replace("    if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; }", "    STAMP(14);\n    if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; if (b < 4) { for (int q = 0; q < %d; q++) a.dbg[b * 17 + q] = T[q]; a.dbg[b * 17 + 16] = it; } }" % NS)
 s = s.replace("    a.lin = h->lin;", "    static long long *dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 4 * 17 * sizeof(long long)); a.dbg = dbg;\n    a.lin = h->lin;")
 assert "#undef LAUNCH_QP\n    return 0;" in s
-s = s.replace("#undef LAUNCH_QP\n    return 0;", "#undef LAUNCH_QP\n    { long long hb[68]; (void)hipMemcpy(hb, dbg, sizeof hb, hipMemcpyDeviceToHost); static int cnt = 0; if (cnt++ % 10 == 5) for (int w = 0; w < 3; w++) { printf(\"[stamps b=%d it=%lld]\", w, hb[w * 17 + 16]); for (int q = 0; q < 16; q++) printf(\" %lld\", hb[w * 17 + q]); printf(\"\\n\"); } }\n    return 0;")
+s = s.replace("#undef LAUNCH_QP\n    return 0;", "#undef LAUNCH_QP\n    { long long hb[68]; (void)hipMemcpy(hb, a.dbg, sizeof hb, hipMemcpyDeviceToHost); static int cnt = 0; if (cnt++ % 10 == 5) for (int w = 0; w < 3; w++) { printf(\"[stamps b=%d it=%lld]\", w, hb[w * 17 + 16]); for (int q = 0; q < 16; q++) printf(\" %lld\", hb[w * 17 + q]); printf(\"\\n\"); } }\n    return 0;")
 open(p, "w").write(s)
 mk = os.path.join(dst, "Makefile"); m = open(mk).read().replace("OUT     = ../libihm2mpc.so", "OUT     = libihm2mpc_dbg.so"); open(mk, "w").write(m)
 subprocess.check_call(["make", "-C", dst, "-j4", "-s"])
