@@ -23,7 +23,7 @@
 #define NLAM 28
 #define MAX_SLOTS 640   // 10 per lane
 #define QM_PAD 16    // >= 2 x ring depth of the vector / forward sweeps: their unclamped prefetch overshoots an instance by < 2 D rows
-#define LIN_REC 88   // doubles per (instance, interval) linearisation record: A (64) | B (16) | b (8)
+#define LIN_REC 96   // doubles per (instance, interval) linearisation record: A (64) | B (16) | b (8) | rb (8: the QP's dynamics residual, riccati_mfma.hpp)
 
 struct ihm2mpc_handle {
     ihm2mpc_config cfg;
@@ -81,7 +81,7 @@ struct ihm2mpc_handle {
     bool lap_wrap;               // prepare_step / step move cars that passed s = L back by one lap first
     double *u0;     // (B,2) first control of the last solve
 
-    double *lin;    // (B,N,88) linearisation records [A | B | b], then B spare records (the kinematic plant's by-product)
+    double *lin;    // (B,N,96) linearisation records [A | B | b | rb], then B spare records (the kinematic plant's by-product)
     // ---- QP workspace in HBM/L2 (everything else of the QP lives in LDS / registers) ----
     double *q_g;    // (B,NS,10) QP gradient
     double *q_P;    // (B,NS,64) Riccati matrices of the current factorisation

@@ -20,17 +20,19 @@
 //     that runs four stages ahead of each sweep (one coalesced wave load per record); P_k and M_k = A - B K_k (512 B each)
 //     are stored once per factorisation; M_k is streamed back by the vector recursion (transposed lane map) and the
 //     forward recursion, P_k is read back in a fully parallel phase.
-//   * the three sequential recursions:
-//       factor   P_k = Gxx - Gux' Guu^-1 Gux          (three LDS hand-offs: W = P[A B], G = H~ + [A B]'W, P/K/M)
-//       vector   p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1})      } carried in REGISTERS: the 8-term contractions
-//       forward  dx_{k+1} = rb_k - B kff_k + M_k dx_k                     } alternate between DPP (inside a group of 8
+//   * the sequential recursions:
+//       factor + predictor's vector recursion: riccati_mfma.hpp -- five v_mfma_f64_16x16x4_f64 per stage, operands and results
+//                chained in registers (P_k, p_k, K_k, kff_k, M_k = A - B K_k and c_k = rb_k - B kff_k from the same products)
+//       vector   p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1})   (corrector) } carried in REGISTERS: the 8-term contractions
+//       forward  dx_{k+1} = c_k + M_k dx_k                                          } alternate between DPP (inside a group of 8
 //     lanes) and DPP + v_permlane16/32_swap (across the groups), so a stage's result is laid out as the next one's operand;
-//     kff_k, du_k and dpi_k are recovered afterwards in parallel over all stages.
+//     du_k and dpi_k (and the corrector's kff_k) are recovered afterwards in parallel over all stages.
 //   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands from LDS (row reads broadcast, column reads
 //     consecutive: conflict-free); wave reductions by DPP / permlane butterflies (VALU speed, no LDS crossbar).
 #include "ihm2mpc_internal.h"
 #include "device_steps.hpp"
 #include "sqp_body.hpp"
+#include "riccati_mfma.hpp"
 
 using namespace ihm2;
 
@@ -69,18 +71,8 @@ struct QpArgs {
 
 __device__ __forceinline__ bool fin(double v) { return fabs(v) < INF_BOUND; }
 
-// Lane exchanges at VALU speed (no LDS crossbar): DPP moves inside a 16-lane row, v_permlane16_swap / v_permlane32_swap
-// (gfx950) across rows and halves.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // every lane of these permutations has an in-range source, so the "old" operand is never used: passing the value itself
-    // saves the two zero-initialising moves a constant would cost per step
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+// Lane exchanges at VALU speed (no LDS crossbar): DPP moves inside a 16-lane row (dpp_mov, riccati_mfma.hpp), v_permlane16_swap /
+// v_permlane32_swap (gfx950) across rows and halves.
 // Butterfly over all 64 lanes: xor 1, xor 2 (quad_perm), mirror inside 8 (row_half_mirror), rotate by 8 inside 16 (row_ror:8),
 // then the row and half swaps -- with both operands equal their two results are "mine" and "the partner's".
 template <typename OP>
@@ -166,106 +158,6 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
     }
 }
 
-// upper-triangle enumeration of a 10x10 symmetric matrix: entry e in [0,55) -> (i <= j)
-__device__ __forceinline__ void sym10_ij(int e, int &i, int &j)
-{
-    int r = 0, rem = e;
-#pragma unroll
-    for (int q = 0; q < 9; q++)
-        if (r == q && rem >= 10 - q) { rem -= 10 - q; r = q + 1; }
-    i = r; j = r + rem;
-}
-
-// Sequential sweep over the stages with the linearisation records streamed from HBM/L2.
-// DIR = -1: k = N-1 .. 0 ; DIR = +1: k = 0 .. N-1.  A register ring holds the next D records (lane e
-// keeps elements e and 64+e of each); the record of the next stage is written to the other LDS slot at
-// the top of a stage, so a load is consumed D-1 stages after it was issued.
-// body(k, rec of stage k, rec of the stage that follows in the sweep, first step) must end with WSYNC().
-template <int DIR, int D, typename F>
-__device__ __forceinline__ void stream_sweep(const double *linb, double *stage2, int N, int lane, F &&body)
-{
-    // All ring loads are UNCONDITIONAL (indices clamped into range): a load under a branch makes the
-    // compiler merge the ring registers through copies and wait for the load right where it is issued.
-    const int l2 = (lane < 24) ? 64 + lane : lane;       // second element of a record owned by this lane
-    double ra[D], rb2[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        const int sd = min(d, N - 1);
-        const int kk = (DIR < 0) ? N - 1 - sd : sd;
-        ra[d] = linb[(size_t)kk * LIN_REC + lane];
-        rb2[d] = linb[(size_t)kk * LIN_REC + l2];
-    }
-    stage2[lane] = ra[0];
-    if (lane < 24) stage2[64 + lane] = rb2[0];
-    WSYNC();
-    for (int s0 = 0; s0 < N; s0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            const int s = s0 + d;
-            const int k = (DIR < 0) ? N - 1 - s : s;
-            double *cur = stage2 + (s & 1) * LIN_REC, *nxt = stage2 + ((s + 1) & 1) * LIN_REC;
-            const double na = ra[(d + 1) % D], nb = rb2[(d + 1) % D];
-            const int sn = min(s + D, N - 1);
-            const int kk = (DIR < 0) ? N - 1 - sn : sn;
-            ra[d] = linb[(size_t)kk * LIN_REC + lane];
-            rb2[d] = linb[(size_t)kk * LIN_REC + l2];
-            if (s < N) {
-                nxt[lane] = na;
-                if (lane < 24) nxt[64 + lane] = nb;
-                body(k, cur, nxt, s == 0);
-            }
-        }
-    }
-}
-
-// Forward sweep over PAIRS of stages whose work does not depend on the previous stage: two records are staged per step
-// (4 LDS slots) and body(k, rec_k, rec_k1, has_k1) treats both, so every LDS wait and the closing fence are shared by two
-// stages.  Ring depth D pairs.  body must end with WSYNC().
-template <int D, typename F>
-__device__ __forceinline__ void stream_pairs(const double *linb, double *stage4, int N, int lane, F &&body)
-{
-    const int l2 = (lane < 24) ? 64 + lane : lane;
-    double ra[D][2], rb2[D][2];
-#pragma unroll
-    for (int d = 0; d < D; d++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int kk = min(2 * d + q, N - 1);
-            ra[d][q] = linb[(size_t)kk * LIN_REC + lane];
-            rb2[d][q] = linb[(size_t)kk * LIN_REC + l2];
-        }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        stage4[q * LIN_REC + lane] = ra[0][q];
-        if (lane < 24) stage4[q * LIN_REC + 64 + lane] = rb2[0][q];
-    }
-    WSYNC();
-    const int NP = (N + 1) / 2;
-    for (int p0 = 0; p0 < NP; p0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            const int p = p0 + d;
-            double *cur = stage4 + (p & 1) * 2 * LIN_REC, *nxt = stage4 + ((p + 1) & 1) * 2 * LIN_REC;
-            double na[2], nb[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                na[q] = ra[(d + 1) % D][q]; nb[q] = rb2[(d + 1) % D][q];
-                const int kk = min(2 * (p + D) + q, N - 1);          // unconditional, clamped (see stream_sweep)
-                ra[d][q] = linb[(size_t)kk * LIN_REC + lane];
-                rb2[d][q] = linb[(size_t)kk * LIN_REC + l2];
-            }
-            if (p < NP) {
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    nxt[q * LIN_REC + lane] = na[q];
-                    if (lane < 24) nxt[q * LIN_REC + 64 + lane] = nb[q];
-                }
-                body(2 * p, cur, cur + LIN_REC, 2 * p + 1 < N);
-            }
-        }
-    }
-}
-
 // The QP of instance b, solved by the calling wavefront (all 64 lanes, lane = threadIdx.x); sm: the block's dynamic LDS.
 // Called by k_qp_wave (one launch per RTI iteration) and by the persistent per-instance loop k_steps.
 template <int NSLOT, int NSOFT, int PATH, int UNI>
@@ -280,12 +172,6 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     // for all stages, python/mpc.py:49-99).  They are then kept in LDS (H only where the budget of 40 KB per instance allows)
     // instead of being fetched through L2 with lane-dependent addresses in every phase.
     constexpr bool HL = UNI && !PATH, CL = UNI;
-    // FUSED (all-hard tables without track rows, i.e. the reference's OCP): the streamed part of the residuals rides on the
-    // factor sweep, which reads the same records -- one pass over the records less per iteration, its instructions fill the
-    // stalls of the Riccati chain; the convergence test then comes after the factorisation (one is wasted per solve).  The
-    // other instantiations keep the separate residual pass.
-    constexpr bool FUSED = (NSOFT == 0) && !PATH;
-
     // ---- LDS carve-up (doubles) ----
     double *z = sm;                  // NS*10  QP iterate
     double *gt = z + NS * 10;        // NS*10  stationarity residual / modified gradient
@@ -295,15 +181,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *gam = rb + N * 8;        // NS*NCK barrier weights per constraint slot
     double *cf = gam + NS * NCK;     // NS*NCK lam_l - lam_u, then gradient coefficients
     double *dz = cf + NS * NCK;      // NS*10  step
-    double *kff = dz + NS * 10;      // N*2
-    double *Kl = kff + N * 2;        // N*16   K_k = Guu^-1 Gux
-    double *Ginv = Kl + N * 16;      // N*4    Guu^-1 (3 used)
-    double *Prb = Ginv + N * 4;      // N*8    P_{k+1} rb_k (same for predictor and corrector)
-    double *stage2 = Prb + N * 8;    // 2*88   staging slots of the streamed records
-    double *Pn = stage2 + 2 * LIN_REC; // 72   P_{k+1}, rows padded to 9: the W phase reads 8 rows at once (stride 8 = 2-way bank conflict)
-    double *Ws = Pn + 72;            // 80     [l][10]
-    double *Gs = Ws + 80;            // 100
-    double *hc = Gs + 100;           // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
+    double *kff = dz + NS * 10;      // N*4    feed-forward terms (2 used per stage)
+    double *Kl = kff + N * 4;        // N*16   K_k = Guu^-1 Gux
+    double *Ginv = Kl + N * 16;      // N*8    Guu^-1 as (Gi0, Gi1, Gi2, Gi1, 0, 0, 0, 0)
+    double *Prb = Ginv + N * 8;      // N*8    after the factor sweep P_{k+1} rb_k + p_{k+1} of the predictor; P_{k+1} rb_k for the corrector
+    double *tile = Prb + N * 8;      // 8*17   transpose tile of the factor sweep
+    double *hc = tile + 136;         // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
     double *Hl = hc + (PATH ? NS * 2 : 0);   // 200  stage and terminal Hessian (HL only)
     double *CDl = Hl + (HL ? 200 : 0);       // 20   general rows (CL only)
 #define HS(k, i, l) (HL ? Hl[(((k) == N) ? 100 : 0) + (i) * 10 + (l)] : a.Hs[((k) * 10 + (i)) * 10 + (l)])
@@ -548,49 +431,14 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; } \
         if (it >= a.iter_max) { qstatus = 1; break; } \
         WSYNC();
-        if (!FUSED) {
-    /*@S:2*/
-            // (ii) [A B]' pi_{k+1} and the dynamics residual, one streamed record per step (no dependency
-            // between stages).  Branch-free: every lane forms one product of each 8x8 part and the 8-term sums
-            // are DPP reductions -- lane (o, l): A[l][o] pi_{k+1}[l] (column o of A) and A[o][l] z_k[l] (row o).
-            // Stages are independent here: two per step (the 4 staging slots overlay stage2 | Pn | Ws | Gs, which only the
-            // factor sweep uses), all LDS reads of both before any write.
-            {
-                const int o = lane >> 3, l = lane & 7;
-                const double m_l2 = (l < 2) ? 1.0 : 0.0, m_o2 = (o < 2) ? 1.0 : 0.0;
-                stream_pairs<2>(linb, stage2, N, lane, [&](int k, const double *AB0, const double *AB1, bool two) {
-                    const double *ABq[2] = {AB0, AB1};
-                    double tp[2], tz[2], bp[2], rbv[2];
-    #pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const double *AB = ABq[q];
-                        const int kq = k + q;
-                        const int kn = min(kq + 1, N);              // stays inside pi / z for the clamped duplicate of an odd tail
-                        const double pl = pi[kn * 8 + l];
-                        tp[q] = sum8(AB[l * 8 + o] * pl);
-                        // row o of [A B] times z_k: lanes l < 2 carry the two input columns as a second product (all lanes
-                        // read, a 0/1 factor selects: cheaper than an exec-mask branch on a single wave)
-                        tz[q] = sum8(fma(AB[64 + o * 2 + (l & 1)] * m_l2, z[kq * 10 + 8 + (l & 1)], AB[o * 8 + l] * z[kq * 10 + l]));
-                        // B' pi_{k+1}: lanes (o < 2, l) hold B[l][o] pi[l]
-                        bp[q] = sum8(AB[64 + l * 2 + (o & 1)] * pl * m_o2);
-                        rbv[q] = tz[q] + AB[80 + o] - z[kn * 10 + o];
-                    }
-                    if (l == 0) {
-    #pragma unroll
-                        for (int q = 0; q < 2; q++) {
-                            if (q == 1 && !two) continue;
-                            const int kq = k + q;
-                            gt[kq * 10 + o] += tp[q];
-                            rb[kq * 8 + o] = rbv[q];
-                            if (o < 2) gt[kq * 10 + 8 + o] += bp[q];
-                        }
-                    }
-                    WSYNC();
-                });
-            }
+        WSYNC();
+/*@S:2*/
+        // (ii) [A B]' pi_{k+1} and the dynamics residual rb_k = A z_k + B u_k + b_k - z_{k+1} (LDS and slot 88 of the record, where
+        // the factor sweep picks it up): one dot product per lane, all stages in parallel
+        dyn_residual(N, lane, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
+        WSYNC();
 /*@S:3*/
-            NORMS_AND_CHECK()
-        }
+        NORMS_AND_CHECK()
         // separate step lengths for the primal (z, t, s) and the dual (pi, lam, lam_s) variables, as HPIPM's split_step
         double alpha = 1.0, alpha_d = 1.0, sigma = 0.0;
 /*@S:4*/
@@ -650,133 +498,31 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 
         };
         slot_coeffs(0);
-        if (!FUSED) add_coeffs();          // FUSED: after the norms below (the convergence test needs the unmodified residual)
+        add_coeffs();
 /*@S:5*/
-            // ---- factorisation: P_k, K_k, Guu^-1, M_k, P_{k+1} rb_k (FUSED: plus the streamed residual terms, one stage ahead
-            // of the Riccati step that needs rb, from the record staged for the next step) ----
-            {
-                {   // terminal stage
-                    const int i = lane >> 3, j = lane & 7;
-                    double v = HS(N, i, j);
-                    if (i == j) v += gam[N * NCK + i];
-                    if (PATH && (i == 1 || i == 2) && (j == 1 || j == 2)) {
-                        const double g12 = gam[N * NCK + 12], g13 = gam[N * NCK + 13], a0 = hc[N * 2], a1 = hc[N * 2 + 1];
-                        v += (i == 1 && j == 1) ? g12 + g13 : (i == 2 && j == 2) ? g12 * a0 * a0 + g13 * a1 * a1 : g12 * a0 - g13 * a1;
-                    }
-                    Pn[(lane >> 3) * 9 + (lane & 7)] = v;
-                    Pg[(size_t)N * 64 + lane] = v;
-                }
-                // this lane's entry of the stage Hessian / general rows, prefetched one stage ahead
-                int gi = 0, gj = 0;
-                if (lane < 55) sym10_ij(lane, gi, gj);
-                // entries of G the track rows touch: (n,n) -> 1, (n,psi) -> 2, (psi,psi) -> 3
-                const int hsel = (lane < 55 && gi == 1 && gj == 1) ? 1 : (lane < 55 && gi + gj == 3 && gi * gj == 2) ? 2 : (lane < 55 && gi == 2 && gj == 2) ? 3 : 0;
-                const int ci = (gi < 8) ? gi : 64 + (gi - 8), si = (gi < 8) ? 8 : 2;      // column gi of [A B] in a record
-                double regH = HS(N - 1, gi, gj);
-                double rc0i = CDV(N - 1, 0, gi), rc0j = CDV(N - 1, 0, gj);
-                double rc1i = CDV(N - 1, 1, gi), rc1j = CDV(N - 1, 1, gj);
-                // second product of the W phase: lanes 0..15 -> B part of W, lanes 16..23 -> P_{k+1} rb_k
-                const int i2 = (lane < 16) ? (lane >> 1) : ((lane < 24) ? lane - 16 : 0);
-                // streamed residual terms of one stage from its record (FUSED): lane (o, l) forms A[l][o] pi_{k+1}[l], A[o][l] z_k[l]
-                // (+ the two input columns on lanes l < 2) and, for o < 2, B[l][o] pi_{k+1}[l]; three DPP sums
-                const int ro = lane >> 3, rl = lane & 7;
-                const double rm_l2 = (rl < 2) ? 1.0 : 0.0, rm_o2 = (ro < 2) ? 1.0 : 0.0;
-                auto resid = [&](int kq, const double *R) {
-                    const double pl = pi[(kq + 1) * 8 + rl];
-                    const double tp = sum8(R[rl * 8 + ro] * pl);
-                    const double tz = sum8(fma(R[64 + ro * 2 + (rl & 1)] * rm_l2, z[kq * 10 + 8 + (rl & 1)], R[ro * 8 + rl] * z[kq * 10 + rl]));
-                    const double bp = sum8(R[64 + rl * 2 + (ro & 1)] * pl * rm_o2);
-                    const double rbv = tz + R[80 + ro] - z[(kq + 1) * 10 + ro];
-                    if (rl == 0) {
-                        gt[kq * 10 + ro] += tp;
-                        rb[kq * 8 + ro] = rbv;
-                        if (ro < 2) gt[kq * 10 + 8 + ro] += bp;
-                    }
-                };
-                stream_sweep<-1, 4>(linb, stage2, N, lane, [&](int k, const double *AB, const double *ABn, bool first) {
-                    if (FUSED) {
-                        if (first) resid(k, AB);
-                        if (k > 0) resid(k - 1, ABn);
-                    }
-                    const double Hk = regH, c0i = rc0i, c0j = rc0j, c1i = rc1i, c1j = rc1j;
-                    if (!UNI && k > 0) {        // stage-dependent data: this lane's entries, fetched one stage ahead
-                        regH = a.Hs[((k - 1) * 10 + gi) * 10 + gj];
-                        rc0i = a.CD[((k - 1) * 2 + 0) * 10 + gi]; rc0j = a.CD[((k - 1) * 2 + 0) * 10 + gj];
-                        rc1i = a.CD[((k - 1) * 2 + 1) * 10 + gi]; rc1j = a.CD[((k - 1) * 2 + 1) * 10 + gj];
-                    }
-                    // W = P_{k+1} [A B]  (64 + 16 entries) and P_{k+1} rb_k (8 entries): two products per lane
-                    {
-                        const int i = lane >> 3, j = lane & 7;
-                        const double *q = (lane < 16) ? AB + 64 + (lane & 1) : rb + k * 8;
-                        const int qs = (lane < 16) ? 2 : 1;
-                        double acc = 0.0, acc2 = 0.0;
-#pragma unroll
-                        for (int l = 0; l < 8; l++) {
-                            acc = fma(Pn[i * 9 + l], AB[l * 8 + j], acc);
-                            acc2 = fma(Pn[i2 * 9 + l], q[l * qs], acc2);
-                        }
-                        Ws[i * 10 + j] = acc;
-                        if (lane < 16) Ws[i2 * 10 + 8 + (lane & 1)] = acc2;
-                        else if (lane < 24) Prb[k * 8 + i2] = acc2;
-                    }
-                    WSYNC();
-                    // G = H~ + [A B]' W  (upper triangle, 55 entries)
-                    if (lane < 55) {
-                        double acc = Hk;
-                        if (gi == gj) acc += gam[k * NCK + gi];
-                        acc = fma(gam[k * NCK + 10] * c0i, c0j, acc);
-                        acc = fma(gam[k * NCK + 11] * c1i, c1j, acc);
-                        if (PATH && hsel) {
-                            const double g12 = gam[k * NCK + 12], g13 = gam[k * NCK + 13], a0 = hc[k * 2], a1 = hc[k * 2 + 1];
-                            acc += (hsel == 1) ? g12 + g13 : (hsel == 2) ? g12 * a0 - g13 * a1 : g12 * a0 * a0 + g13 * a1 * a1;
-                        }
-                        // all 16 operands first: issued back to back they cost one LDS latency, not eight
-                        double av[8], wv[8];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) { av[l] = AB[ci + l * si]; wv[l] = Ws[l * 10 + gj]; }
-#pragma unroll
-                        for (int l = 0; l < 8; l++) acc = fma(av[l], wv[l], acc);
-                        Gs[gi * 10 + gj] = acc;
-                        Gs[gj * 10 + gi] = acc;
-                    }
-                    WSYNC();
-                    // P_k = Gxx - Gux' Guu^-1 Gux ; K_k = Guu^-1 Gux ; closed-loop matrix M_k = A - B K_k (streamed back by the
-                    // vector recursion, which reads it with the transposed lane map -- the same 512 bytes -- and by the
-                    // forward recursion).  One phase: every lane forms the two entries of K it needs from the G column it
-                    // has already read.
-                    {
-                        const double g00 = Gs[88], g01 = Gs[89], g11 = Gs[99];
-                        const int i0 = lane >> 3, j0 = lane & 7;
-                        const int i = min(i0, j0), j = max(i0, j0);      // evaluate the symmetric pair identically
-                        const double ai = Gs[i * 10 + 8], bi = Gs[i * 10 + 9], cj = Gs[j * 10 + 8], dj = Gs[j * 10 + 9];
-                        const double gij = Gs[i * 10 + j];
-                        const double a_own = AB[lane], b0 = AB[64 + i0 * 2], b1 = AB[64 + i0 * 2 + 1];
-                        const double idet = 1.0 / (g00 * g11 - g01 * g01);
-                        const double Gi0 = g11 * idet, Gi1 = -g01 * idet, Gi2 = g00 * idet;
-                        const double v = gij - (ai * (Gi0 * cj + Gi1 * dj) + bi * (Gi1 * cj + Gi2 * dj));
-                        Pn[(lane >> 3) * 9 + (lane & 7)] = v;
-                        Pg[(size_t)k * 64 + lane] = v;
-                        const double gx0 = (j0 == i) ? ai : cj, gx1 = (j0 == i) ? bi : dj;      // G[j0][8], G[j0][9]
-                        const double K0 = Gi0 * gx0 + Gi1 * gx1, K1 = Gi1 * gx0 + Gi2 * gx1;     // K[0][j0], K[1][j0]
-                        if (lane < 16) Kl[k * 16 + lane] = (lane < 8) ? K0 : K1;
-                        if (lane == 0) { Ginv[k * 4 + 0] = Gi0; Ginv[k * 4 + 1] = Gi1; Ginv[k * 4 + 2] = Gi2; }
-                        Mg[(size_t)k * 64 + lane] = a_own - b0 * K0 - b1 * K1;
-                    }
-                    WSYNC();
-                });
-            }
-
-        if (FUSED) {
-            NORMS_AND_CHECK()
+        // ---- factorisation and the predictor's vector recursion: P_k, M_k -> HBM/L2; K_k, Guu^-1, p_k, kff_k, c_k = rb_k - B kff_k
+        // and P_{k+1} rb_k + p_{k+1} -> LDS (riccati_mfma.hpp).  The records' rb slots were written by this wave: wait for them. ----
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+        {
+            RicLds L;
+            L.gam = (int)(gam - sm); L.hc = (int)(hc - sm); L.gt = (int)(gt - sm); L.pv = (int)(pv - sm); L.hv = (int)(Prb - sm);
+            L.Kl = (int)(Kl - sm); L.Ginv = (int)(Ginv - sm); L.kff = (int)(kff - sm); L.dz = (int)(dz - sm); L.tile = (int)(tile - sm);
+            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC);
+            if (lane < 8) dz[lane] = 0.0;
+            WSYNC();
         }
 #undef NORMS_AND_CHECK
         for (int pass = 0; pass < 2; pass++) {
             const double mu_t = fmax(sigma * mu, mu_floor);
             if (pass == 1) slot_coeffs(1);
-            if (FUSED || pass == 1) add_coeffs();
+            if (pass == 1) {
+            add_coeffs();
 /*@S:6*/
-            // ---- vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) ----
+            // ---- corrector's vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) (the predictor's came out of
+            // the factor sweep, which left P_{k+1} rb_k + p_{k+1}: take the predictor's p_{k+1} out again) ----
             // the part without p_{k+1} for all stages in parallel ...
+            for (int e = lane; e < N * 8; e += 64) Prb[e] -= pv[e + 8];
+            WSYNC();
             for (int e = lane; e < NS * 8; e += 64) {
                 const int k = e >> 3, j = e & 7;
                 double v = gt[k * 10 + j];
@@ -792,7 +538,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             {
                 const int g = lane >> 3, w = lane & 7;
                 double pw = pv[N * 8 + w], pg = 0.0;
-                stream_rows<-1, 8, 4>(Mg, N, (w << 3) | g, lane,
+                stream_rows<-1, 8, 4>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
                     [&](int k, bool odd, double &prb, double &base) { prb = Prb[k * 8 + (odd ? g : w)]; base = pv[k * 8 + (odd ? w : g)]; },
                     [&](int k, double m, bool odd, double prb, double base) {
                         if (!odd) {
@@ -820,15 +566,16 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     g0 = fma(Bk[l * 2 + 0], h, g0);
                     g1 = fma(Bk[l * 2 + 1], h, g1);
                 }
-                const double kf0 = Ginv[k * 4 + 0] * g0 + Ginv[k * 4 + 1] * g1;
-                const double kf1 = Ginv[k * 4 + 1] * g0 + Ginv[k * 4 + 2] * g1;
-                kff[k * 2 + 0] = kf0;
-                kff[k * 2 + 1] = kf1;
+                const double kf0 = Ginv[k * 8 + 0] * g0 + Ginv[k * 8 + 1] * g1;
+                const double kf1 = Ginv[k * 8 + 1] * g0 + Ginv[k * 8 + 2] * g1;
+                kff[k * 4 + 0] = kf0;
+                kff[k * 4 + 1] = kf1;
 #pragma unroll
                 for (int i = 0; i < 8; i++) dz[(k + 1) * 10 + i] = rb[k * 8 + i] - Bk[i * 2] * kf0 - Bk[i * 2 + 1] * kf1;
             }
             if (lane < 8) dz[lane] = 0.0;
             WSYNC();
+            }
 
 /*@S:9*/
             // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k, same alternating register layout ----
@@ -836,7 +583,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             {
                 const int g = lane >> 3, w = lane & 7;
                 double dxw = dz[w], dxg = 0.0;
-                stream_rows<+1, 8, 4>(Mg, N, lane, (w << 3) | g,
+                stream_rows<+1, 8, 4>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
                     [&](int k, bool odd, double &c, double &unused) { c = dz[(k + 1) * 10 + (odd ? w : g)]; unused = 0.0; },
                     [&](int k, double m, bool odd, double c, double) {
                         if (!odd) {
@@ -856,7 +603,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 const int k = e >> 1, aa = e & 1;
                 double acc = 0.0;
                 if (k < N) {
-                    acc = -kff[k * 2 + aa];
+                    acc = -kff[k * 4 + aa];
 #pragma unroll
                     for (int l = 0; l < 8; l++) acc = fma(-Kl[k * 16 + aa * 8 + l], dz[k * 10 + l], acc);
                 }
@@ -867,7 +614,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     const int k = e >> 3, i = e & 7;
                     double acc = pv[e];
 #pragma unroll
-                    for (int l = 0; l < 8; l++) acc = fma(Pg[(size_t)k * 64 + i * 8 + l], dz[k * 10 + l], acc);
+                    for (int l = 0; l < 8; l++) acc = fma(Pg[(size_t)k * 64 + RIC_IDX(i, l)], dz[k * 10 + l], acc);
                     pv[e] = acc;        // dpi_k = P_k dx_k + p_k
                 }
             }
@@ -1169,8 +916,7 @@ static size_t qp_lds_bytes(const ihm2mpc_handle *h)
     const size_t N = h->N, NS = h->NS;
     const int nck = h->path_on ? 14 : 12;
     const int uni = h->uniform_H && h->uniform_CD;
-    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 2 + 16 + 4 + 8) + 2 * LIN_REC + 72 + 80 + 100 +
-                             (uni ? 20 + (h->path_on ? 0 : 200) : 0));
+    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 4 + 16 + 8 + 8) + 136 + (uni ? 20 + (h->path_on ? 0 : 200) : 0));
 }
 
 static QpArgs qp_args(ihm2mpc_handle *h)

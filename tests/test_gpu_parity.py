@@ -466,7 +466,11 @@ def test_other_horizons_match_oracle(track, Nh, B):
         status = s.solve()
         out = P.rti_step(x, u, x0, yref, yref_e, pi=pi, lam=lam)
         pi, lam = out["pi"], out["lam"]
-        np.testing.assert_array_equal(status, out["status"])
+        # a QP that diverges (the terminal box of quirk Q1 is infeasible for some x0) ends as NaN (1) or as a failed QP (4)
+        # depending on where the overflow hits first -- the matrix-core factor sweep sums in another order than the oracle;
+        # both mean "failed" to the reference (python/main.py:326).  Solved instances must agree exactly.
+        same = (status == out["status"]) | (np.isin(status, (1, 4)) & np.isin(out["status"], (1, 4)))
+        assert same.all(), (status, out["status"])
         ok = status == 0
         np.testing.assert_array_equal(s.get_qp_iter()[ok], out["qp_iter"][ok])
         assert ok.sum() >= (0.8 * B if Nh >= 5 else 1)      # tiny horizons: the terminal box (quirk Q1) is infeasible for some x0, on both sides
