@@ -184,7 +184,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *kff = dz + NS * 10;      // N*4    feed-forward terms (2 used per stage)
     double *Kl = kff + N * 4;        // N*16   K_k = Guu^-1 Gux
     double *Ginv = Kl + N * 16;      // N*8    Guu^-1 as (Gi0, Gi1, Gi2, Gi1, 0, 0, 0, 0)
-    double *Prb = Ginv + N * 8;      // N*8    after the factor sweep P_{k+1} rb_k + p_{k+1} of the predictor; P_{k+1} rb_k for the corrector
+    double *Prb = Ginv + N * 8;      // N*8    P_{k+1} rb_k (same for predictor and corrector)
     double *tile = Prb + N * 8;      // 8*17   transpose tile of the factor sweep
     double *hc = tile + 136;         // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
     double *Hl = hc + (PATH ? NS * 2 : 0);   // 200  stage and terminal Hessian (HL only)
@@ -368,7 +368,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     int qstatus = 1, it = 0;
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
     double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
-    double dla_l[NSLOT], dla_u[NSLOT], dta_l[NSLOT], dta_u[NSLOT];
+    double pa_l[NSLOT], pa_u[NSLOT];      // dlam * dt of the predictor (only the products enter the corrector): 2 registers per slot less than the factors
     for (it = 0;; it++) {
 /*@S:1*/
         // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
@@ -394,12 +394,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             }
             SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));     // the two halves of a split slot share a lane
         }
+/*@S:14*/
         WSYNC();
         // ---- stationarity and dynamics residuals ----
         // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
-        for (int e = lane; e < NS * 10; e += 64) {
+        auto stat_local = [&](const int e, double acc) {
             const int k = e / 10, j = e % 10;
-            double acc = gb[e];
 #pragma unroll
             for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
             if (k < N) {
@@ -412,7 +412,24 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 const double l12 = cf[k * NCK + 12], l13 = cf[k * NCK + 13];
                 acc -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
             }
-            gt[e] = acc;
+            return acc;
+        };
+        {
+            // the first GBR passes unrolled: every value is formed before the first one is stored, so the QP gradient entries (HBM/L2:
+            // read one per pass, each pass waited a full L2 latency) and the LDS operands of all passes are in flight together
+            constexpr int GBR = 7;
+            double sv[GBR];
+#pragma unroll
+            for (int q = 0; q < GBR; q++) {
+                const int e = min(lane + 64 * q, NS * 10 - 1);
+                sv[q] = stat_local(e, gb[e]);
+            }
+#pragma unroll
+            for (int q = 0; q < GBR; q++) {
+                const int e = lane + 64 * q;
+                if (e < NS * 10) gt[e] = sv[q];
+            }
+            for (int e = lane + 64 * GBR; e < NS * 10; e += 64) gt[e] = stat_local(e, gb[e]);
         }
 #define NORMS_AND_CHECK() \
  \
@@ -435,7 +452,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 /*@S:2*/
         // (ii) [A B]' pi_{k+1} and the dynamics residual rb_k = A z_k + B u_k + b_k - z_{k+1} (LDS and slot 88 of the record, where
         // the factor sweep picks it up): one dot product per lane, all stages in parallel
-        dyn_residual(N, lane, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
+        dyn_residual<4>(N, lane, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
         WSYNC();
 /*@S:3*/
         NORMS_AND_CHECK()
@@ -460,7 +477,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     const double gm = lm / tt, gs = so_ls[q] / so_s[q], D = so_Zw[q] + gm + gs;
                     double c1, c2, rsv;
                     if (pass == 0) { c1 = (lm * tt + lm * rdv) / tt; c2 = so_ls[q]; rsv = so_rs[q]; gam[s_kc[r]] += gm * (so_Zw[q] + gs) / D; }
-                    else { c1 = ((al ? dla_l[r] * dta_l[r] : dla_u[r] * dta_u[r]) - mu_t) / tt; c2 = (so_pa[q] - mu_t) / so_s[q]; rsv = 0.0; }
+                    else { c1 = ((al ? pa_l[r] : pa_u[r]) - mu_t) / tt; c2 = (so_pa[q] - mu_t) / so_s[q]; rsv = 0.0; }
                     c = c1 - gm * (rsv + c1 + c2) / D;
                     cf[s_kc[r]] += al ? c : -c;
                     continue;
@@ -472,8 +489,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     if (au) c -= fma(gu, rd_u[r], lam_u[r]);
                     SLOT_ACC(gam[s_kc[r]], gl + gu);
                 } else {
-                    if (al) c += (dla_l[r] * dta_l[r] - mu_t) / t_l[r];
-                    if (au) c -= (dla_u[r] * dta_u[r] - mu_t) / t_u[r];
+                    if (al) c += (pa_l[r] - mu_t) / t_l[r];
+                    if (au) c -= (pa_u[r] - mu_t) / t_u[r];
                 }
                 SLOT_ACC(cf[s_kc[r]], c);
             }
@@ -501,13 +518,15 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         add_coeffs();
 /*@S:5*/
         // ---- factorisation and the predictor's vector recursion: P_k, M_k -> HBM/L2; K_k, Guu^-1, p_k, kff_k, c_k = rb_k - B kff_k
-        // and P_{k+1} rb_k + p_{k+1} -> LDS (riccati_mfma.hpp).  The records' rb slots were written by this wave: wait for them. ----
+        // and P_{k+1} rb_k -> LDS (riccati_mfma.hpp).  The records' rb slots were written by this wave: wait for them. ----
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
         {
+            // offsets of the carve-up above as plain integers (a difference of two generic pointers into LDS makes the compiler
+            // build both flat addresses -- and mis-fold their null checks in the register-starved instantiations)
             RicLds L;
-            L.gam = (int)(gam - sm); L.hc = (int)(hc - sm); L.gt = (int)(gt - sm); L.pv = (int)(pv - sm); L.hv = (int)(Prb - sm);
-            L.Kl = (int)(Kl - sm); L.Ginv = (int)(Ginv - sm); L.kff = (int)(kff - sm); L.dz = (int)(dz - sm); L.tile = (int)(tile - sm);
-            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC);
+            L.gt = NS * 10; L.pv = NS * 28; L.gam = NS * 36 + N * 8; L.dz = L.gam + 2 * NS * NCK; L.kff = L.dz + NS * 10; L.Kl = L.kff + N * 4;
+            L.Ginv = L.Kl + N * 16; L.hv = L.Ginv + N * 8; L.tile = L.hv + N * 8; L.hc = L.tile + 136;
+            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0);
             if (lane < 8) dz[lane] = 0.0;
             WSYNC();
         }
@@ -519,10 +538,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             add_coeffs();
 /*@S:6*/
             // ---- corrector's vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) (the predictor's came out of
-            // the factor sweep, which left P_{k+1} rb_k + p_{k+1}: take the predictor's p_{k+1} out again) ----
+            // the factor sweep) ----
             // the part without p_{k+1} for all stages in parallel ...
-            for (int e = lane; e < N * 8; e += 64) Prb[e] -= pv[e + 8];
-            WSYNC();
             for (int e = lane; e < NS * 8; e += 64) {
                 const int k = e >> 3, j = e & 7;
                 double v = gt[k * 10 + j];
@@ -609,13 +626,27 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 }
                 dz[k * 10 + 8 + aa] = acc;
             }
+/*@S:16*/
             if (want_dpi) {
-                for (int e = lane; e < NS * 8; e += 64) {
-                    const int k = e >> 3, i = e & 7;
-                    double acc = pv[e];
+                // dpi_k = P_k dx_k + p_k.  P_k is symmetric: column i of its RIC_IDX layout holds the pairs (P[l][i], P[l+4][i])
+                // adjacent -- four 16-byte loads per entry, those of three entries in flight before the first is used
+                const int n = NS * 8;
+                for (int base = 0; base < n; base += 192) {
+                    double2 pr[3][4];
 #pragma unroll
-                    for (int l = 0; l < 8; l++) acc = fma(Pg[(size_t)k * 64 + RIC_IDX(i, l)], dz[k * 10 + l], acc);
-                    pv[e] = acc;        // dpi_k = P_k dx_k + p_k
+                    for (int q = 0; q < 3; q++) {
+                        const int e = min(base + 64 * q + lane, n - 1), k = e >> 3, i = e & 7;
+#pragma unroll
+                        for (int l = 0; l < 4; l++) pr[q][l] = *reinterpret_cast<const double2 *>(Pg + (size_t)k * 64 + RIC_IDX(l, i));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const int e = base + 64 * q + lane, ec = min(e, n - 1), k = ec >> 3;
+                        double acc = pv[ec];
+#pragma unroll
+                        for (int l = 0; l < 4; l++) { acc = fma(pr[q][l].x, dz[k * 10 + l], acc); acc = fma(pr[q][l].y, dz[k * 10 + l + 4], acc); }
+                        if (e < n) pv[e] = acc;        // dpi_k = P_k dx_k + p_k
+                    }
                 }
             }
             WSYNC();
@@ -634,7 +665,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     const double lm = al ? lam_l[r] : lam_u[r], tt = al ? t_l[r] : t_u[r], rdv = al ? rd_l[r] : rd_u[r];
                     const double y = al ? drz : -drz;
                     const double gm = lm / tt, gs = so_ls[q] / so_s[q], D = so_Zw[q] + gm + gs;
-                    const double rm1 = (pass == 0) ? lm * tt : lm * tt + (al ? dla_l[r] * dta_l[r] : dla_u[r] * dta_u[r]) - mu_t;
+                    const double rm1 = (pass == 0) ? lm * tt : lm * tt + (al ? pa_l[r] : pa_u[r]) - mu_t;
                     const double rm2 = (pass == 0) ? so_ls[q] * so_s[q] : so_ls[q] * so_s[q] + so_pa[q] - mu_t;
                     const double c1 = (rm1 + lm * rdv) / tt, c2 = rm2 / so_s[q];
                     const double dsv = -(so_rs[q] + c1 + c2) / D - gm / D * y;
@@ -650,7 +681,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     continue;
                 }
                 if (fin(s_dl[r])) {
-                    const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + dla_l[r] * dta_l[r] - mu_t;
+                    const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + pa_l[r] - mu_t;
                     dt_l[r] = drz + rd_l[r];
                     if (NSOFT == 0) {       // all-hard tables: one reciprocal per side, step bound as 1 / max(-dt / t)
                         const double it = 1.0 / t_l[r];
@@ -664,7 +695,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     }
                 }
                 if (fin(s_du[r])) {
-                    const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + dla_u[r] * dta_u[r] - mu_t;
+                    const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + pa_u[r] - mu_t;
                     dt_u[r] = -drz + rd_u[r];
                     if (NSOFT == 0) {
                         const double it = 1.0 / t_u[r];
@@ -678,6 +709,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     }
                 }
             }
+/*@S:15*/
             // hard sides collect max(-dt/t), max(-dlam/lam) (>= 1 matters only); soft sides the step bounds themselves
             if (NSOFT == 0) { amax = fmin(amax, 1.0 / rmax); amax_d = fmin(amax_d, 1.0 / rmax_d); }
             amax = wave_min(amax); amax_d = wave_min(amax_d);
@@ -685,7 +717,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 if (a.m_act == 0) { alpha = alpha_d = 1.0; break; }
 #pragma unroll
                 for (int r = 0; r < NSLOT; r++) {
-                    dla_l[r] = dlam_l[r]; dla_u[r] = dlam_u[r]; dta_l[r] = dt_l[r]; dta_u[r] = dt_u[r];
+                    pa_l[r] = dlam_l[r] * dt_l[r]; pa_u[r] = dlam_u[r] * dt_u[r];
                     if (s_kc[r] < 0) continue;
                     if (fin(s_dl[r])) mu_aff += (lam_l[r] + amax_d * dlam_l[r]) * (t_l[r] + amax * dt_l[r]);
                     if (fin(s_du[r])) mu_aff += (lam_u[r] + amax_d * dlam_u[r]) * (t_u[r] + amax * dt_u[r]);

@@ -78,8 +78,8 @@ struct RicLds {
     int gam;      // (NS,NCK) barrier weights per constraint row
     int hc;       // (NS,2)   track-row slopes (PATH)
     int gt;       // (NS,10)  in: modified gradient of the predictor
-    int pv;       // (NS,8)   out: p_k
-    int hv;       // (N,8)    out: P_{k+1} rb_k + p_{k+1}
+    int pv;       // (NS,8)   out: p_N, and p_k (k < N) if store_p
+    int hv;       // (N,8)    out: P_{k+1} rb_k
     int Kl;       // (N,16)   out: K_k
     int Ginv;     // (N,8)    out: Guu^-1 as (Gi0, Gi1, Gi2, Gi1, 0 ..)
     int kff;      // (N,4)    out: kff_k (2 used)
@@ -88,49 +88,82 @@ struct RicLds {
 };
 
 // rb_k = A_k z_k + B_k u_k + b_k - z_{k+1} (-> LDS and the record's slot) and gt_k += [A B]_k' pi_{k+1}, all stages in parallel:
-// one dot product per lane, no reductions.
+// one dot product per lane, no reductions.  The record entries of a BATCH of dot products are loaded before any of them is used
+// (the wave is alone on its SIMD: a load that is consumed at once costs its full L2 latency, and the compiler cannot batch the
+// loads itself across the stores in between).  What bounds the phase is the number of cache lines its scattered loads touch (a
+// lane's row / column of [A B] lies in other lines than its neighbour's); staging the records through LDS with coalesced loads
+// was tried and lost to LDS bank conflicts (rows 64 bytes apart: 16-way), measured 29 k cycles against 10 k.
+template <int NB>
 __device__ __forceinline__ void dyn_residual(const int N, const int lane, double *linb, const double *z, const double *pi, double *gt, double *rb,
                                              const int lin_rec)
 {
-    for (int e = lane; e < N * 8; e += 64) {
-        const int k = e >> 3, o = e & 7;
-        double *rec = linb + (size_t)k * lin_rec;
-        double acc = rec[80 + o] - z[(k + 1) * 10 + o];
+    const int n1 = N * 8;
+    for (int base = 0; base < n1; base += 64 * NB) {
+        double2 Ar[NB][4], Br[NB];
+        double br[NB];
 #pragma unroll
-        for (int l = 0; l < 8; l++) acc = fma(rec[o * 8 + l], z[k * 10 + l], acc);
-        acc = fma(rec[64 + o * 2], z[k * 10 + 8], acc);
-        acc = fma(rec[64 + o * 2 + 1], z[k * 10 + 9], acc);
-        rb[e] = acc;
-        rec[RIC_REC_RB + o] = acc;
+        for (int q = 0; q < NB; q++) {
+            const int e = min(base + 64 * q + lane, n1 - 1), k = e >> 3, o = e & 7;
+            const double *rec = linb + (size_t)k * lin_rec;
+            const double2 *row = reinterpret_cast<const double2 *>(rec + o * 8);
+#pragma unroll
+            for (int l = 0; l < 4; l++) Ar[q][l] = row[l];
+            Br[q] = *reinterpret_cast<const double2 *>(rec + 64 + o * 2);
+            br[q] = rec[80 + o];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int e = base + 64 * q + lane, ec = min(e, n1 - 1), k = ec >> 3, o = ec & 7;
+            double acc = br[q] - z[(k + 1) * 10 + o];
+#pragma unroll
+            for (int l = 0; l < 4; l++) { acc = fma(Ar[q][l].x, z[k * 10 + 2 * l], acc); acc = fma(Ar[q][l].y, z[k * 10 + 2 * l + 1], acc); }
+            acc = fma(Br[q].x, z[k * 10 + 8], acc);
+            acc = fma(Br[q].y, z[k * 10 + 9], acc);
+            if (e < n1) {
+                rb[e] = acc;
+                linb[(size_t)k * lin_rec + RIC_REC_RB + o] = acc;
+            }
+        }
     }
-    for (int e = lane; e < N * 10; e += 64) {
-        const int k = e / 10, jz = e % 10;
-        const double *rec = linb + (size_t)k * lin_rec;
-        const double *col = (jz < 8) ? rec + jz : rec + 64 + (jz - 8);
-        const int cs = (jz < 8) ? 8 : 2;
-        double acc = gt[e];
+    const int n2 = N * 10;
+    for (int base = 0; base < n2; base += 64 * NB) {
+        double cr[NB][8];
 #pragma unroll
-        for (int l = 0; l < 8; l++) acc = fma(col[l * cs], pi[(k + 1) * 8 + l], acc);
-        gt[e] = acc;
+        for (int q = 0; q < NB; q++) {
+            const int e = min(base + 64 * q + lane, n2 - 1), k = e / 10, jz = e - k * 10;
+            const double *rec = linb + (size_t)k * lin_rec;
+            const double *col = (jz < 8) ? rec + jz : rec + 64 + (jz - 8);
+            const int cs = (jz < 8) ? 8 : 2;
+#pragma unroll
+            for (int l = 0; l < 8; l++) cr[q][l] = col[l * cs];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            const int e = base + 64 * q + lane, ec = min(e, n2 - 1), k = ec / 10;
+            double acc = gt[ec];
+#pragma unroll
+            for (int l = 0; l < 8; l++) acc = fma(cr[q][l], pi[(k + 1) * 8 + l], acc);
+            if (e < n2) gt[e] = acc;
+        }
     }
 }
 
 // Backward sweep.  In (LDS): gam, hc, gt = the predictor's gradient incl. [A B]'pi; in the records: A, B and rb (slot 88).
-// Out: LDS arrays of RicLds; HBM: Pg (NS,64), Mg (N,64) in the RIC_IDX layout.
+// Out: LDS arrays of RicLds; HBM: Pg (NS,64), Mg (N,64) in the RIC_IDX layout.  store_p (wave-uniform): also keep p_k, k < N.
 // Hs (NS,10,10), CD (N,2,10): batch-shared; UNI: the same for all k < N.  D: depth of the record prefetch ring.
 template <int NCK, bool PATH, bool UNI, int D>
 __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, const double *__restrict__ linb, const double *__restrict__ Hs,
                                                    const double *__restrict__ CD, const RicLds L, double *__restrict__ Pg, double *__restrict__ Mg,
-                                                   const int lin_rec)
+                                                   const int lin_rec, const bool store_p)
 {
     const int g = lane >> 4, j = lane & 15;
     const int col = (j < 10) ? j : (j == 12) ? 9 : (j == 13) ? 8 : -1;
     const int row[4] = {g, g + 4, (g < 2) ? 8 + g : -1, (g == 0) ? 9 : (g == 1) ? 8 : -1};
     const double m10 = (j == 10) ? 1.0 : 0.0;
-    // an LDS-typed pointer: every access below is a ds_ instruction by type, whatever the address-space inference makes of the caller
+    // the block's dynamic LDS, indexed directly: every access below is a ds_ instruction by construction (a pointer variable, even an
+    // LDS-typed one, made the register-starved instantiations go through generic-pointer casts the compiler then mis-folded)
     extern __shared__ double ric_sm[];
-    typedef __attribute__((address_space(3))) double lds_double_t;
-    lds_double_t *const sm = (lds_double_t *)ric_sm;
+#define sm ric_sm
 
     // ---- per-lane constants: record offsets, Hessian entries, LDS addresses ----
     unsigned off[2], offB;
@@ -193,11 +226,19 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
         const double *rec = linb + (size_t)max(N - 1 - d, 0) * lin_rec;
         r0[d] = rec[off[0]]; r1[d] = rec[off[1]]; rB[d] = rec[offB];
     }
-    // C operand of a stage's G product, prepared one stage ahead (its LDS reads then precede the stage's own LDS stores)
+    // C operand of a stage's G product, prepared one stage ahead in two halves: the LDS reads are issued right after the stage's last
+    // matrix instruction (before the stage's own LDS stores, whose addresses the compiler cannot tell apart), the arithmetic follows
+    // once the transposed P has come back -- the reads' latency and the tile's round trip are covered by the stage's stores
     d4_t Hc;
-    auto prepare = [&](const int k) {
-        const double val[4] = {sm[va[0]], sm[va[0] + 4], sm[va[0] + 8], sm[va[3]]};      // rows g, g + 4, 8 + g; the mirrored input row
-        const double g10 = sm[a_g10], g11 = sm[a_g10 + 1];
+    double val[4], g10, g11, pg12 = 0.0, pg13 = 0.0, pa0 = 0.0, pa1 = 0.0;
+    auto prepare_load = [&](const int k) {
+        val[0] = sm[va[0]]; val[1] = sm[va[0] + 4]; val[2] = sm[va[0] + 8]; val[3] = sm[va[3]];      // rows g, g + 4, 8 + g; the mirrored input row
+        g10 = sm[a_g10]; g11 = sm[a_g10 + 1];
+        if (PATH) { pg12 = sm[a_g10 + 2]; pg13 = sm[a_g10 + 3]; pa0 = sm[L.hc + k * 2]; pa1 = sm[L.hc + k * 2 + 1]; }
+        a_g10 -= NCK;
+        va[0] -= vstride[0]; va[3] -= vstride[3];
+    };
+    auto prepare_compute = [&](const int k) {
         double hk[4], c0k[4], c1k[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { hk[r] = hconst[r]; c0k[r] = cc0[r]; c1k[r] = cc1[r]; }
@@ -212,14 +253,10 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) Hc[r] = fma(g11, c1k[r], fma(g10, c0k[r], fma(dsel[r], val[r], hk[r])));
-        if (PATH) {
-            const double g12 = sm[a_g10 + 2], g13 = sm[a_g10 + 3], a0 = sm[L.hc + k * 2], a1 = sm[L.hc + k * 2 + 1];
-            Hc[0] += p11 * (g12 + g13) + p12 * (g12 * a0 - g13 * a1) + p22 * (g12 * a0 * a0 + g13 * a1 * a1);
-        }
-        a_g10 -= NCK;
-        va[0] -= vstride[0]; va[3] -= vstride[3];
+        if (PATH) Hc[0] += p11 * (pg12 + pg13) + p12 * (pg12 * pa0 - pg13 * pa1) + p22 * (pg12 * pa0 * pa0 + pg13 * pa1 * pa1);
     };
-    prepare(N - 1);
+    prepare_load(N - 1);
+    prepare_compute(N - 1);
     RIC_STAMP_DECL
     for (int s0 = 0; s0 < N; s0 += D) {
 #pragma unroll
@@ -231,7 +268,8 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
                 const double B0 = r0[d], B1 = r1[d], Bmk = rB[d];
                 const d4_t Hk = Hc;
                 // ---- W = P_{k+1} [A B rb] + p_{k+1} on the affine column ----
-                d4_t W = {m10 * Pd[0], m10 * Pd[1], 0.0, 0.0};
+                const double q0 = m10 * Pd[0], q1 = m10 * Pd[1];
+                d4_t W = {q0, q1, 0.0, 0.0};
                 W = IHM2_MFMA_F64(Pd[0], B0, W);
                 W = IHM2_MFMA_F64(Pd[1], B1, W);
                 RIC_STAMP(1);
@@ -241,16 +279,13 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
                 G = IHM2_MFMA_F64(B1, W[1], G);
                 RIC_STAMP(2);
                 // ---- K = Guu^-1 [G(u0,:); G(u1,:)]; the adjugate part runs beside the reciprocal of the determinant ----
-                const double g00 = readlane_f64(G[2], 8), g01 = readlane_f64(G[2], 9), g11 = readlane_f64(G[2], 25);
-                const double det = g00 * g11 - g01 * g01;
+                const double g00 = readlane_f64(G[2], 8), g01 = readlane_f64(G[2], 9), g11u = readlane_f64(G[2], 25);
+                const double det = g00 * g11u - g01 * g01;
                 double idet = __builtin_amdgcn_rcp(det);       // hardware reciprocal + two Newton steps (det of an SPD block)
-                const double cAa = selA0 * g11 + selA2 * g00, cBa = selB * g01;
+                const double cAa = selA0 * g11u + selA2 * g00, cBa = selB * g01;
                 const double ta = cAa * G[2] + cBa * G[3];
                 idet = fma(fma(-det, idet, 1.0), idet, idet);
                 idet = fma(fma(-det, idet, 1.0), idet, idet);
-#ifdef RIC_IEEE_DIV
-                idet = 1.0 / det;
-#endif
                 const double Kf = ta * idet;
                 RIC_STAMP(3);
                 // ---- [P_k p_k; M_k c_k] = [Gxx; A rb] - [Gxu; B] K ----
@@ -260,38 +295,42 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
                 RIC_STAMP(4);
                 // ---- P_k := (P_k + P_k') / 2 through an LDS tile: the recursion is only as good as P's symmetry (with the open-loop
                 // unstable dynamic model the antisymmetric rounding noise decided whether ill-conditioned QPs converged; the
-                // reference implementation evaluates symmetric pairs identically) ----
+                // reference implementation evaluates symmetric pairs identically).  The tile's round trip is covered by the work
+                // that does not depend on it: the ring refill, the next stage's LDS operands, this stage's stores. ----
                 sm[a_tw] = S[0]; sm[a_tw + 4 * 17] = S[1];
-                RIC_WSYNC();
-                const double T0 = sm[a_tr], T1 = sm[a_tr + 4];
-                Pd[0] = fma(wT, T0, wS * S[0]);
-                Pd[1] = fma(wT, T1, wS * S[1]);
-                // ---- refill ring slot d (D stages ahead), prepare the next stage's C operand ----
                 {
                     const double *rec = linb + (size_t)max(k - D, 0) * lin_rec;
                     r0[d] = rec[off[0]]; r1[d] = rec[off[1]]; rB[d] = rec[offB];
                 }
-                if (k > 0) prepare(k - 1);
+                if (k > 0) prepare_load(k - 1);
                 RIC_STAMP(5);
-                // ---- results of stage k ----
 #ifndef RIC_SKIP_A
                 if (j < 8) {
-                    double2 pp, mm;
-                    pp.x = Pd[0]; pp.y = Pd[1]; mm.x = S[2]; mm.y = S[3];
-                    *(double2 *)(Pg + (size_t)k * 64 + RIC_IDX(g, j)) = pp;
+                    double2 mm;
+                    mm.x = S[2]; mm.y = S[3];
                     *(double2 *)(Mg + (size_t)k * 64 + RIC_IDX(g, j)) = mm;
-#ifndef RIC_SKIP_K
                     if (g < 2) sm[L.Kl + k * 16 + g * 8 + j] = Kf;
-#endif
                 }
 #endif
 #ifndef RIC_SKIP_B
                 if (j == 10) {
-                    sm[L.hv + k * 8 + g] = W[0]; sm[L.hv + k * 8 + 4 + g] = W[1];
-                    sm[L.pv + k * 8 + g] = S[0]; sm[L.pv + k * 8 + 4 + g] = S[1];
+                    sm[L.hv + k * 8 + g] = W[0] - q0; sm[L.hv + k * 8 + 4 + g] = W[1] - q1;        // P_{k+1} rb_k
+                    if (store_p) { sm[L.pv + k * 8 + g] = S[0]; sm[L.pv + k * 8 + 4 + g] = S[1]; }
                     sm[L.dz + (k + 1) * 10 + g] = S[2]; sm[L.dz + (k + 1) * 10 + 4 + g] = S[3];
                     sm[L.Ginv + k * 8 + 2 * g] = cAa * idet; sm[L.Ginv + k * 8 + 2 * g + 1] = cBa * idet;
                     sm[L.kff + k * 4 + g] = Kf;
+                }
+#endif
+                RIC_WSYNC();
+                const double T0 = sm[a_tr], T1 = sm[a_tr + 4];
+                Pd[0] = fma(wT, T0, wS * S[0]);
+                Pd[1] = fma(wT, T1, wS * S[1]);
+                if (k > 0) prepare_compute(k - 1);
+#ifndef RIC_SKIP_A
+                if (j < 8) {
+                    double2 pp;
+                    pp.x = Pd[0]; pp.y = Pd[1];
+                    *(double2 *)(Pg + (size_t)k * 64 + RIC_IDX(g, j)) = pp;
                 }
 #endif
                 RIC_STAMP(6);
@@ -299,6 +338,7 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
         }
     }
     RIC_STAMP_OUT;
+#undef sm
 }
 
 }  // namespace ihm2

@@ -41,10 +41,10 @@ __global__ __launch_bounds__(64) void k_proto(int N, Off o, double *lin_all, con
     for (int r = 0; r < reps; r++) {
         long long tq = __builtin_readcyclecounter();
         if (r > 0) { for (int e = lane; e < (N + 1) * 10; e += 64) sm[o.gt + e] = lds_in[o.gt + e]; __syncthreads(); }
-        dyn_residual(N, lane, lin, sm + o.z, sm + o.pi, sm + o.gt, sm + o.rb, REC);
+        dyn_residual<4>(N, lane, lin, sm + o.z, sm + o.pi, sm + o.gt, sm + o.rb, REC);
         __syncthreads();
         if (r == 0) t0 = __builtin_readcyclecounter(), tr += t0 - tq;
-        riccati_sweep_mfma<NCK, PATHV != 0, UNIV != 0, RD>(N, lane, lin, Hs, CD, L, Pg + (size_t)b * (N + 1) * 64, Mg + (size_t)b * N * 64, REC);
+        riccati_sweep_mfma<NCK, PATHV != 0, UNIV != 0, RD>(N, lane, lin, Hs, CD, L, Pg + (size_t)b * (N + 1) * 64, Mg + (size_t)b * N * 64, REC, true);
         __syncthreads();
     }
     long long t1 = __builtin_readcyclecounter();
@@ -127,8 +127,8 @@ int main(int argc, char **argv)
         double W[8][10], G[10][10], gv[10];
         for (int i = 0; i < 8; i++) for (int jz = 0; jz < 10; jz++) { double s = 0; for (int l = 0; l < 8; l++) s += Pn[i * 8 + l] * AB(l, jz); W[i][jz] = s; }
         for (int i = 0; i < 10; i++) for (int jz = 0; jz < 10; jz++) { double s = Ht(k, i, jz); for (int l = 0; l < 8; l++) s += AB(l, i) * W[l][jz]; G[i][jz] = s; }
-        for (int i = 0; i < 8; i++) { double s = 0; for (int l = 0; l < 8; l++) s += Pn[i * 8 + l] * rb[k * 8 + l]; hv[k * 8 + i] = s + pv[(k + 1) * 8 + i]; }
-        for (int jz = 0; jz < 10; jz++) { double s = gt[k * 10 + jz]; for (int l = 0; l < 8; l++) s += AB(l, jz) * hv[k * 8 + l]; gv[jz] = s; }
+        for (int i = 0; i < 8; i++) { double s = 0; for (int l = 0; l < 8; l++) s += Pn[i * 8 + l] * rb[k * 8 + l]; hv[k * 8 + i] = s; }
+        for (int jz = 0; jz < 10; jz++) { double s = gt[k * 10 + jz]; for (int l = 0; l < 8; l++) s += AB(l, jz) * (hv[k * 8 + l] + pv[(k + 1) * 8 + l]); gv[jz] = s; }
         const double det = G[8][8] * G[9][9] - G[8][9] * G[8][9];
         const double Gi0 = G[9][9] / det, Gi1 = -G[8][9] / det, Gi2 = G[8][8] / det;
         Gi[k * 8] = Gi0; Gi[k * 8 + 1] = Gi1; Gi[k * 8 + 2] = Gi2; Gi[k * 8 + 3] = Gi1;
