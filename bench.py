@@ -69,11 +69,33 @@ def flops_per_solve(n_ipm):
     return lin, qp
 
 
-def cpu_baseline(ocp, track, x0_all, budget_s=12.0):
-    """Oracle (own C restatement, OpenMP over instances) on a bounded sample of the same workload."""
+def cpu_baseline(ocp, track, x0_all, budget_s=12.0, gpu_state=None, device=0):
+    """Oracle (own C restatement, OpenMP over instances) on a bounded sample of the same workload; with gpu_state (the iterate,
+    multipliers and plant state of a sample of instances AFTER the timed region) also the same-run check of SURVEY.md 8d: one
+    more control step of that sample on the GPU and in the oracle, deviation of the two results."""
     from oracle import oracle as orc
 
     P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+    check = None
+    if gpu_state is not None:
+        from ihm2_amd.solver import BatchedOcpSolver
+
+        xs, us, x0s, pis, lams = (np.ascontiguousarray(a) for a in gpu_state)
+        Bs = xs.shape[0]
+        small = BatchedOcpSolver(ocp, Bs, track.s_ref, track.kappa_ref, device=device)
+        small.set_x(xs); small.set_u(us); small.set_x0(x0s); small.set_multipliers(pis, lams)
+        small.prepare_step(S_TARGET)
+        st_g = small.solve()
+        xo, uo = xs.copy(), us.copy()
+        yref, yref_e = orc.prepare_step(N_H, x0s, S_TARGET, xo, uo)
+        out = P.rti_step(xo, uo, x0s, yref, yref_e, pi=pis, lam=lams)
+        ok = (st_g == 0) & (out["status"] == 0)
+        rel = lambda a, b: float(np.max(np.abs(a - b) / (1.0 + np.abs(b)))) if a.size else 0.0
+        check = {"instances": int(Bs), "both_status_0": int(ok.sum()), "status_equal": bool(np.array_equal(st_g, out["status"])),
+                 "qp_iter_equal": bool(np.array_equal(small.get_qp_iter()[ok], out["qp_iter"][ok])),
+                 "max_rel_dev_x": rel(small.get_x()[ok], xo[ok]), "max_rel_dev_u": rel(small.get_u()[ok], uo[ok]),
+                 "max_rel_dev_kkt_residuals": rel(small.get_residuals(), out["res"])}
+        small.free()
     # the GPU box grants this job a 16-core CPU share per GPU; IHM2_CPU_THREADS overrides
     threads = int(os.environ.get("IHM2_CPU_THREADS", min(orc.num_threads(), len(os.sched_getaffinity(0)), 16)))
     Bs = min(512, x0_all.shape[0])
@@ -97,7 +119,7 @@ def cpu_baseline(ocp, track, x0_all, budget_s=12.0):
         steps += 1
     return {"value": solves / t_acc, "unit": "solves/s", "cores": threads, "kind": "port",
             "sample": f"{Bs} instances x {steps} RTI steps of the same workload ({t_acc:.1f} s of CPU work), "
-                      f"oracle/libihm2_oracle.so with OpenMP over instances; own CPU restatement, not acados"}
+                      f"oracle/libihm2_oracle.so with OpenMP over instances; own CPU restatement, not acados"}, check
 
 
 def main():
@@ -110,10 +132,20 @@ def main():
     ap.add_argument("--per-step-launches", action="store_true",
                     help="one launch per phase and step (ihm2mpc_step) instead of the persistent per-instance loop (ihm2mpc_run_steps)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--lib", default=None, help="path of a diagnostic build of libihm2mpc.so (tools/build_variant.sh); default: the product library")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2],
+                    help="BASELINE.json configs[.]: 1 = batch 1024 kinematic (the metric's configuration); 2 = batch 8192 dynamic bicycle with "
+                         "soft nonlinear track rows, reported as written (fdyn6) and with un-crossed slip angles (fdyn6u)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N>1 path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     args = ap.parse_args()
+    if args.lib:
+        from ihm2_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(args.lib)
+    if args.config == 2:
+        return main_config2(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -265,17 +297,20 @@ def main():
                 kname, kms, kflops = "k_qp_wave", ms_qp, f_qp * B
         achieved = kflops / (kms * 1e-3) / 1e12
         alg_bytes = 8 * (2 * (N_H + 1) * 8 + 2 * N_H * 2 + 8 + 5)          # 6632 B per solve
-        # HBM traffic per launch of the dominant kernel: PMC counters (FETCH_SIZE, WRITE_SIZE) cannot be read from
-        # inside this process; they come from the committed rocprofv3 --pmc passes of this same command
+        # HBM traffic per launch of the dominant kernel: PMC counters (FETCH_SIZE, WRITE_SIZE) cannot be read from inside this
+        # process; the per-solve figure comes from the committed rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 5`
+        # (profiles/r2/bench_traffic.json, corrected as MI355X_MICROARCH.md prescribes) and is scaled by the solves of this launch
         traffic, traffic_src = None, None
         try:
-            prof = os.path.join(ROOT, "profiles", "r1", "current_summary.json")
-            kk = json.load(open(prof))["kernels"]
-            key = [n for n in kk if n.startswith(kname.split("<")[0])][0]
-            if B == 1024 and (not persistent or kk[key].get("steps_per_launch") == args.steps):
-                traffic, traffic_src = kk[key]["hbm_traffic_bytes_per_launch"], "profiles/r1/current_summary.json"
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "bench_traffic.json")))
+            key = "k_steps" if persistent else kname
+            if B == tj["batch"] and key in tj["bytes_per_solve"]:
+                traffic = tj["bytes_per_solve"][key] * B * (args.steps if persistent else 1)
+                traffic_src = f"profiles/r2/bench_traffic.json ({tj['command']}): {tj['bytes_per_solve'][key]:.0f} B per solve x solves of this launch"
         except Exception:
             pass
+        res_all = solver.get_residuals()        # NLP KKT inf-norms (stationarity, dynamics, inequalities, complementarity) at the iterates of the last step
+        kkt = {"stat": float(res_all[:, 0].max()), "eq": float(res_all[:, 1].max()), "ineq": float(res_all[:, 2].max()), "comp": float(res_all[:, 3].max())}
         out = {
             "metric": "NMPC RTI solves/s (batch), N=40, nx=8 (6-DOF bicycle), fkin6",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -285,12 +320,13 @@ def main():
                                    f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 read-back to pinned host memory; "
                                    + ("all steps in one launch, every instance on its own wavefront (ihm2mpc_run_steps)" if persistent else "one launch per phase and step (ihm2mpc_step)"),
                        "batch_per_gpu": B, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards"},
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes * B * (args.steps if persistent else 1),
                          "launch": f"{args.steps} control steps x {B} instances in one launch (persistent per-instance loop)" if persistent else "one RTI iteration of the batch",
-                         "note": "fp64 VALU/latency-bound path (no MFMA on it): peak = MI355X fp64 vector = fp64 matrix "
-                                 "peak; achieved = algorithmic flops (SURVEY.md 8d model) / HIP-event kernel time",
+                         "note": "fp64 path bound by instruction issue / latency of one wave per SIMD; linearisation on the fp64 vector "
+                                 "pipe, the QP's Riccati factor on v_mfma_f64_16x16x4_f64; peak = MI355X fp64 vector = fp64 matrix peak; "
+                                 "achieved = algorithmic flops (SURVEY.md 8d model) / HIP-event kernel time",
                          "kernel_ms": kms, "linearize_ms": ms_lin, "qp_ms": ms_qp, "n_ipm_mean": n_ipm, "M": M_SUB,
                          "alg_flops_per_solve": f_lin + f_qp,
                          "hbm_fraction_algorithmic": alg_bytes * value / world / 1e9 / HBM_PEAK_GBS,
@@ -299,16 +335,49 @@ def main():
             "latency_ms_p50_single": float(np.percentile(b1_ms, 50)), "latency_ms_p99_single": float(np.percentile(b1_ms, 99)),
             "status_counts": {str(k): int(v) for k, v in enumerate(np.bincount(status_all, minlength=5)) if v},
             "gather_ms": gather_ms,
+            "max_kkt_residual": kkt,
             "qp_iter_percentiles": {"p50": float(np.percentile(qp_iters, 50)), "p90": float(np.percentile(qp_iters, 90)),
                                     "p99": float(np.percentile(qp_iters, 99)), "max": int(np.max(qp_iters))},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(ocp, track, x0, args.cpu_budget)
+            ns = min(64, B)
+            pi_g, lam_g = solver.get_multipliers()
+            state = (solver.get_x()[:ns], solver.get_u()[:ns], solver.get_x0()[:ns], pi_g[:ns], lam_g[:ns])
+            out["cpu_baseline"], chk = cpu_baseline(ocp, track, x0, args.cpu_budget, gpu_state=state, device=device)
+            out["max_rel_dev_vs_oracle"] = max(chk["max_rel_dev_x"], chk["max_rel_dev_u"])
+            out["oracle_check"] = chk
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     solver.free()
+
+
+def main_config2(args):
+    """BASELINE.json configs[2]: batch 8192, dynamic bicycle (Pacejka tyres), N = 40, soft nonlinear track rows, one GPU.
+    Launches per phase and step (the persistent loop has no dynamic-model instantiation).  Both the model as written (quirk Q3:
+    crossed slip angles, open-loop unstable -- most QPs are infeasible) and the named deviation fdyn6u are run and reported."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from measure_configs import rti_throughput
+
+    B = args.batch if args.batch != 1024 else 8192
+    steps, warmup = min(args.steps, 50), min(args.warmup, 10)
+    var = {}
+    for model, kw in (("fdyn6", dict(track_rows="soft")), ("fdyn6u", dict(terminal_bounds="stage", track_rows="soft", recover=True))):
+        r = rti_throughput(model=model, B=B, steps=steps, warmup=warmup, **kw)
+        var[model] = {k: r[k] for k in ("solves_per_s", "ms_per_step", "linearize_ms", "qp_ms", "ok_fraction", "status", "qp_iter_mean", "terminal_bounds", "recover")}
+    r = var["fdyn6"]
+    print(json.dumps({
+        "metric": "NMPC RTI solves/s (batch), N=40, nx=8 (6-DOF dynamic bicycle, Pacejka), fdyn6 + soft track rows",
+        "value": r["solves_per_s"], "unit": "solves/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[2]: batch={B} dynamic bicycle fdyn6 as written (python/models.py:455-606), N=40, dt=0.05, RK4 x M=25, soft nonlinear "
+                               "track rows 100/100 (old/generate_acaods_interface.py:191-212,380-449), track fsds_competition_1; launches per phase and step",
+                   "batch_per_gpu": B, "N": N_H, "M": M_SUB},
+        "success_fraction": r["ok_fraction"],
+        "variants": var,
+        "note": "value = the model as written; its QPs are mostly infeasible (open-loop unstable, DESIGN.md section 2). variants.fdyn6u = "
+                "un-crossed slip angles (named deviation), stage terminal box, re-initialisation of failed instances"}))
 
 
 if __name__ == "__main__":

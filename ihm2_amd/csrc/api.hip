@@ -108,6 +108,9 @@ int field_info(ihm2mpc_handle *h, const char *field, FieldInfo *fi)
 
 }  // namespace
 
+// classical RK4 is stable for |z| < 2.785 on the negative real axis: z = -(dt / M) / t for the first-order actuator lags
+static bool rk4_unstable(double dt, int M) { return dt / M / 1e-3 >= 2.78; }
+
 extern "C" {
 
 const char *ihm2mpc_last_error(void) { return g_err.c_str(); }
@@ -119,6 +122,10 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     if (cfg->batch < 1) return fail("batch must be >= 1");
     if (cfg->N < 2 || cfg->N > IHM2MPC_NMAX) return fail("N must be in [2, %d]", IHM2MPC_NMAX);
     if (cfg->M < 1) return fail("M must be >= 1");
+    if (rk4_unstable(cfg->dt, cfg->M))
+        return fail("RK4 with %d sub-step(s) of dt = %g is unstable on the actuator lags (t_T = 1e-3 s, t_delta = 0.02 s: |z| = dt / (M t) must stay "
+                    "below 2.78): use M >= %d (the reference's sim_method_num_steps = 1 belongs to its IRK integrator, python/main.py:234-236)",
+                    cfg->M, cfg->dt, (int)ceil(cfg->dt / (2.78 * 1e-3)));
     if (cfg->model < IHM2MPC_MODEL_FKIN6 || cfg->model > IHM2MPC_MODEL_FDYN6U) return fail("unknown OCP model %d", cfg->model);
     if (cfg->ntracks < 1 || cfg->nknots < 2) return fail("need at least one track table with >= 2 knots");
     if (!(cfg->dt > 0.0)) return fail("dt must be positive");
@@ -154,6 +161,10 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
     DA(xc, B * 8); DA(s_guess, B);
     DA(step_args, 32);
+    for (int i = 0; i < 2; i++) {      // pinned staging of the persistent loop's argument blocks (uploaded without a host wait)
+        HIP_TRY(hipHostMalloc(&h->args_host[i], 1024, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&h->args_ev[i], hipEventDisableTiming));
+    }
     DA(Wd, N * 144 + 64); DA(st_lb, NS * NC); DA(st_ub, NS * NC); DA(st_sz, NS * NLAM); DA(st_sZ, NS * NLAM);
     h->sqp_globalization = 0; h->sqp_use_suff = 0; h->sqp_full_step_dual = 0;
     h->sqp_alpha_min = 0.05; h->sqp_alpha_red = 0.7; h->sqp_eps = 1e-4;
@@ -184,6 +195,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 2; i++) { if (h->args_host[i]) (void)hipHostFree(h->args_host[i]); if (h->args_ev[i]) (void)hipEventDestroy(h->args_ev[i]); }
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -711,6 +723,7 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (!x || !u || !x_next) return fail("null argument");
     if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
     if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
@@ -724,6 +737,7 @@ int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim)
     CHECK_H(h);
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream, h->active_set ? h->active : nullptr);
     HIP_TRY(hipGetLastError());
@@ -780,6 +794,7 @@ int ihm2mpc_set_active(ihm2mpc_handle *h, const int32_t *active)
 {
     CHECK_H(h);
     h->active_set = active != nullptr;
+    h->freeze_armed = false;      // set_active(NULL) also forgets the mask a frozen loop left behind
     if (active) {
         HIP_TRY(hipMemcpyAsync(h->active, active, (size_t)h->B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -792,6 +807,7 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     CHECK_H(h);
     if (ready(h)) return -1;
     if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     // The plant step and the reference ramp only feed the QP (through x0 and yref); the warm-start shift and the
     // linearisation only need the previous iterate.  Two branches, joined in front of the QP kernel.
@@ -841,14 +857,16 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
     CHECK_H(h);
     if (ready(h)) return -1;
     if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     if (n_steps < 1) return fail("n_steps must be >= 1");
     const size_t B = h->B, n = n_steps;
     if (ihm2mpc_reserve_history(h, n_steps)) return -1;
-    if (freeze && !h->active_set) {       // every car starts driving
+    if (freeze && !h->active_set && !h->freeze_armed) {       // every car starts driving; later calls keep the mask the device updated
         std::vector<int32_t> ones(B, 1);
         HIP_TRY(hipMemcpyAsync(h->active, ones.data(), B * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        h->freeze_armed = true;
     }
     // The persistent loop pays off while every instance has a wavefront slot of its own (the QP's 40 KB of LDS allow 4 per CU):
     // a larger batch would run in rounds of whole n_steps-long loops, whereas launches per step backfill the slots of finished

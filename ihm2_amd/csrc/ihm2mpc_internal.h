@@ -78,6 +78,7 @@ struct ihm2mpc_handle {
     int32_t *status, *qp_iter;   // (B)
     int32_t *active;             // (B) plant mask of the device-resident closed loop (nullptr-equivalent while !active_set)
     bool active_set;
+    bool freeze_armed;           // a run_steps(freeze) call initialised the mask: later calls keep what the device made of it
     bool lap_wrap;               // prepare_step / step move cars that passed s = L back by one lap first
     double *u0;     // (B,2) first control of the last solve
 
@@ -100,6 +101,9 @@ struct ihm2mpc_handle {
     int32_t *ls_done, *ls_status, *ls_iter, *ls_qp_acc;
     double *step_args;              // device copy of the persistent loop's own argument block (256 B), allocated with the handle
     double *ls_args;                // device copy of the line search's argument block for the persistent loop (512 B)
+    void *args_host[2];             // pinned staging of both blocks (1 KB each), used alternately
+    hipEvent_t args_ev[2];          // recorded after a slot's upload: the slot is free again once it has passed
+    int args_idx;
 
     // ---- history of ihm2mpc_run_steps, grown on demand ----
     size_t hist_cap;                // steps the buffers hold

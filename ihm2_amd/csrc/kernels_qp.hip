@@ -29,6 +29,8 @@
 //     du_k and dpi_k (and the corrector's kff_k) are recovered afterwards in parallel over all stages.
 //   * 8x8 / 8x10 / 10x10 products: one output entry per lane, operands from LDS (row reads broadcast, column reads
 //     consecutive: conflict-free); wave reductions by DPP / permlane butterflies (VALU speed, no LDS crossbar).
+#include <cstring>
+
 #include "ihm2mpc_internal.h"
 #include "device_steps.hpp"
 #include "sqp_body.hpp"
@@ -398,8 +400,11 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         WSYNC();
         // ---- stationarity and dynamics residuals ----
         // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
-        auto stat_local = [&](const int e, double acc) {
+        // (an unrolled variant that forms all values before the first store -- QP gradient entries and LDS operands of all passes in
+        // flight together -- was 30 % faster here but cost the slot phases twice that in spilled slot registers)
+        for (int e = lane; e < NS * 10; e += 64) {
             const int k = e / 10, j = e % 10;
+            double acc = gb[e];
 #pragma unroll
             for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
             if (k < N) {
@@ -412,24 +417,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 const double l12 = cf[k * NCK + 12], l13 = cf[k * NCK + 13];
                 acc -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
             }
-            return acc;
-        };
-        {
-            // the first GBR passes unrolled: every value is formed before the first one is stored, so the QP gradient entries (HBM/L2:
-            // read one per pass, each pass waited a full L2 latency) and the LDS operands of all passes are in flight together
-            constexpr int GBR = 7;
-            double sv[GBR];
-#pragma unroll
-            for (int q = 0; q < GBR; q++) {
-                const int e = min(lane + 64 * q, NS * 10 - 1);
-                sv[q] = stat_local(e, gb[e]);
-            }
-#pragma unroll
-            for (int q = 0; q < GBR; q++) {
-                const int e = lane + 64 * q;
-                if (e < NS * 10) gt[e] = sv[q];
-            }
-            for (int e = lane + 64 * GBR; e < NS * 10; e += 64) gt[e] = stat_local(e, gb[e]);
+            gt[e] = acc;
         }
 #define NORMS_AND_CHECK() \
  \
@@ -863,14 +851,14 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             const int st = a.status[b];
             if (st != 0 && st != 2) act = false;
         }
-        if (!act) { stop_from(step); return; }
+        if (!act && s.freeze) { stop_from(step); return; }        // without freeze a masked car keeps solving, only its plant stands still (as ihm2mpc_step)
         if (s.lap_wrap) { dev_wrap_lap(b, lane, N, s.nknots, s.s_ref, a.track_id, s.x0, a.x); __syncthreads(); }
         const double x_old = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
         // The kinematic plant (model 0) is one more "interval" of the linearisation -- lane N integrates (x0, u0) with the
         // code of the interval lanes, in lockstep with them -- so it costs no time; the dynamic plants take a phase of their own.
         const bool kin_plant = s.model == IHM2MPC_MODEL_FKIN6;
         double *spare = s.lin + (size_t)B * N * LIN_REC;
-        if (!kin_plant) {
+        if (!kin_plant && act) {
             if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
             __syncthreads();
         }
@@ -893,7 +881,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             }
             {
                 const int tid = a.track_id[b];
-                const bool with_plant = kin_plant && it == 0;
+                const bool with_plant = kin_plant && it == 0 && act;
                 for (int k = lane; k < N + (with_plant ? 1 : 0); k += 64) {
                     const bool plant = k == N;
                     const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
@@ -1001,10 +989,19 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     // every field of s is set: upload it (and the line search's block in the SQP mode)
     static_assert(sizeof(StepArgs) <= 32 * sizeof(double), "step_args holds 256 bytes");
     static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
-    const LsArgs ls_host = make_ls_args(h);
-    if (sqp && hipMemcpyAsync(h->ls_args, &ls_host, sizeof(LsArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
-    if (hipMemcpyAsync(h->step_args, &s, sizeof(StepArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
-    (void)hipStreamSynchronize(h->stream);      // s and ls_host leave scope
+    // both blocks go through a pinned staging slot (two slots, used alternately) and are uploaded in stream order: the host does
+    // not wait for the previous launch (run_steps(wait = false) enqueues in pieces while the host does other work)
+    const int slot = (h->args_idx++) & 1;
+    if (hipEventSynchronize(h->args_ev[slot]) != hipSuccess) return 1;          // the upload that last used this slot has been issued long ago
+    char *stage = (char *)h->args_host[slot];
+    std::memcpy(stage, &s, sizeof(StepArgs));
+    if (hipMemcpyAsync(h->step_args, stage, sizeof(StepArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+    if (sqp) {
+        const LsArgs ls_host = make_ls_args(h);
+        std::memcpy(stage + 512, &ls_host, sizeof(LsArgs));
+        if (hipMemcpyAsync(h->ls_args, stage + 512, sizeof(LsArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+    }
+    if (hipEventRecord(h->args_ev[slot], h->stream) != hipSuccess) return 1;
     const StepArgs *sdev = (const StepArgs *)h->step_args;
     const LsArgs *ls = (const LsArgs *)h->ls_args;
     const int uni = h->uniform_H && h->uniform_CD;

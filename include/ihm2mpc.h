@@ -215,17 +215,6 @@ int ihm2mpc_host_alloc(uint64_t nbytes, void **p);
 int ihm2mpc_host_free(void *p);
 int ihm2mpc_get_u0_async(ihm2mpc_handle *h, double *pinned_dst);
 
-/* n_steps control steps of the MiL loop (python/main.py:476-517: plant, reference ramp + shift, one RTI iteration) in ONE
- * launch: every instance runs its steps back to back on its own wavefront, so no instance waits for the slowest QP of the
- * batch at every step (throughput follows the mean interior-point iteration count instead of the maximum).  Results are
- * those of n_steps calls of ihm2mpc_step.  The persistent loop exists for the fkin6 OCP -- all-hard constraint tables (the
- * reference's OCP) and soft / track-row tables with batch-shared weights and rows, in the RTI and the SQP mode --
- * and pays off while every instance has a wavefront of its own (batch <= 4 per compute unit); any other case runs
- * n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
- * freeze != 0: the rules of the reference's loop per car -- a solve status other than 0 / 2 (python/main.py:326-328) or a NaN
- * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
- * ihm2mpc_set_active is updated accordingly.  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant
- * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block). */
 /* IHM2Controller.compute_control (python/main.py:297-334) in ONE call for the whole batch: x0 (B,8) in, reference ramp +
  * warm-start shift + solve (one RTI iteration, or the configured SQP iterations), u0 (B,2) and status (B, may be NULL) out;
  * one host-device round trip and one wait -- the call of a real-time controller (mpc_control_node.cpp:105-255). */
@@ -233,6 +222,20 @@ int ihm2mpc_compute_control(ihm2mpc_handle *h, const double *x0, double s_target
 /* device room for the histories of up to n_steps steps (run_steps grows it on demand; reserving keeps the allocations out of
  * a timed call) */
 int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps);
+/* n_steps control steps of the MiL loop (python/main.py:476-517: plant, reference ramp + shift, one RTI iteration) in ONE
+ * launch: every instance runs its steps back to back on its own wavefront, so no instance waits for the slowest QP of the
+ * batch at every step (throughput follows the mean interior-point iteration count instead of the maximum).  Results are
+ * those of n_steps calls of ihm2mpc_step -- bit for bit for batches of more than 3 instances; ihm2mpc_step, ihm2mpc_solve and
+ * ihm2mpc_compute_control linearise batches of up to 128 intervals (batch <= 3 at N = 40) one sensitivity column per wavefront
+ * (the latency path of the single real-time controller), whose records agree with the loop's to 1e-15, not bit for bit.  The persistent loop exists for the fkin6 OCP -- all-hard constraint tables (the
+ * reference's OCP) and soft / track-row tables with batch-shared weights and rows, in the RTI and the SQP mode --
+ * and pays off while every instance has a wavefront of its own (batch <= 4 per compute unit); any other case runs
+ * n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
+ * freeze != 0: the rules of the reference's loop per car -- a solve status other than 0 / 2 (python/main.py:326-328) or a NaN
+ * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
+ * ihm2mpc_set_active is updated accordingly and kept across calls until ihm2mpc_set_active(NULL).  freeze == 0: a car masked
+ * by ihm2mpc_set_active keeps solving, only its plant stands still (as in ihm2mpc_step).  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant
+ * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block). */
 int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target, int32_t n_steps, int32_t freeze,
                       double lap_stop, double *u0_hist, double *x0_hist, int32_t *status_hist, int32_t *qp_iter_hist);
 

@@ -1,0 +1,199 @@
+"""GPU parity / property tests of the BASELINE.json configurations that round 1 left untested:
+
+* the benchmarked entry point itself -- the persistent per-instance loop ``ihm2mpc_run_steps`` -- directly against an oracle loop
+  (not only bit-equality with the per-step path);
+* configs[3]'s workload: dynamic bicycle (as written and un-crossed), per-instance ``track_id`` over every track of ``data/``
+  the table builder takes, against the oracle;
+* full-size property runs of configs[1] (B = 1024 kinematic) and configs[2] (B = 8192 dynamic + soft track rows): statuses, NLP KKT
+  residuals of the QP that was solved, bounds respected by the iterate.
+
+Floating point: tolerances are written at each assert (north star: 1e-5 relative on state / control)."""
+import numpy as np
+import pytest
+from conftest import make_ocp, sample_x0
+
+pytestmark = pytest.mark.gpu
+
+N = 40
+ALL_TRACKS = ("fsds_competition_1", "fsds_competition_2", "fsds_competition_3", "fsds_default", "acceleration", "skidpad", "short_skidpad")
+
+
+def _rel(a, b, floor=1.0):
+    return float(np.max(np.abs(a - b) / (floor + np.abs(b)))) if a.size else 0.0
+
+
+def test_persistent_loop_matches_oracle_loop(track):
+    """ihm2mpc_run_steps (the kernel bench.py times): plant -> shift + ramp -> linearise -> QP, 12 steps of 96 instances in ONE
+    launch, against the same loop driven by the oracle: controls, plant states, statuses and IPM iteration counts of every step."""
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    B, steps, M_sim = 96, 12, 25
+    ocp = make_ocp()
+    s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, B, seed=2024)
+    s.set_x0(x0); s.init_guess()
+    x, u = s.get_x(), s.get_u()
+    # a first solve without the plant on both sides: the loop starts from a control
+    s.prepare_step(40.0); st = s.solve()
+    yref, yref_e = orc.prepare_step(N, x0, 40.0, x, u)
+    out = P.rti_step(x, u, x0, yref, yref_e)
+    np.testing.assert_array_equal(st, out["status"])
+    pi, lam = out["pi"], out["lam"]
+    h = s.run_steps(40.0, steps, model=0, M_sim=M_sim, u0_hist=True, x0_hist=True, status_hist=True, qp_iter_hist=True)
+    xc = x0.copy()
+    for i in range(steps):
+        xc = P.sim_step(xc, u[:, 0].copy(), 0, M_sim)
+        yref, yref_e = orc.prepare_step(N, xc, 40.0, x, u)
+        out = P.rti_step(x, u, xc, yref, yref_e, pi=pi, lam=lam)
+        pi, lam = out["pi"], out["lam"]
+        assert _rel(h["x0"][i], xc) < 1e-7, i                   # plant state the step was solved from (tolerance 1e-7 relative)
+        np.testing.assert_array_equal(h["status"][i], out["status"])
+        assert np.all(out["status"] == 0)
+        assert np.mean(h["qp_iter"][i] == out["qp_iter"]) >= 0.97, i      # a marginal convergence test may fall either way after several steps
+        assert _rel(h["u0"][i], u[:, 0]) < 1e-6, i              # tolerance 1e-6 relative (north star: 1e-5)
+    assert _rel(s.get_x(), x) < 1e-6 and _rel(s.get_u(), u) < 1e-6
+
+
+def _accepted_tracks():
+    """Every data/ track the table builder takes (three of the seven are open paths)."""
+    from ihm2_amd.track import track_table
+
+    ok, why = [], {}
+    for name in ALL_TRACKS:
+        try:
+            ok.append((name, track_table(name)))
+        except Exception as e:      # noqa: BLE001 -- the reason is reported by the test
+            why[name] = repr(e)
+    return ok, why
+
+
+@pytest.mark.parametrize("model", ["fdyn6", "fdyn6u"])
+def test_config3_dynamic_model_over_all_tracks_matches_oracle(model):
+    """BASELINE.json configs[3] (the per-GPU share, small): dynamic bicycle, instance b on track b mod T over every track of data/
+    the table builder accepts, soft nonlinear track rows, against the oracle with the same per-instance track ids."""
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    plans, why = _accepted_tracks()
+    assert len(plans) >= 4, why                       # at least the four closed FSDS tracks
+    names = [n for n, _ in plans]
+    print("tracks accepted:", names, "rejected:", why)
+    B = 12 * len(plans)
+    ocp = make_ocp(model=model)
+    ocp.model.con_h_expr = "track"
+    c = ocp.constraints
+    c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+    c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+    ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+    ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+    s_ref = np.stack([p.s_ref for _, p in plans]); k_ref = np.stack([p.kappa_ref for _, p in plans])
+    widths = np.array([[p.right_widths.min(), p.left_widths.min()] for _, p in plans])
+    tid = (np.arange(B) % len(plans)).astype(np.int32)
+    s = BatchedOcpSolver(ocp, B, s_ref, k_ref, track_id=tid, track_widths=widths)
+    P = orc.OracleProblem(ocp.flatten().as_dict(s_ref, k_ref, track_widths=widths))
+    x0 = np.zeros((B, 8))
+    for t, (_, p) in enumerate(plans):
+        sel = tid == t
+        x0[sel] = sample_x0(p, int(sel.sum()), seed=300 + t)
+    x0[:, 3] = np.clip(x0[:, 3], 4.0, 12.0)
+    s.set_x0(x0); s.init_guess()
+    x, u = s.get_x(), s.get_u()
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+    s.set_yref(yref); s.set_yref_e(yref_e); s.set_multipliers(None, None)
+    pi = lam = None
+    for it in range(2):
+        st = s.solve()
+        out = P.rti_step(x, u, x0, yref, yref_e, track_id=tid, pi=pi, lam=lam)
+        pi, lam = out["pi"], out["lam"]
+        # failed instances may end as NaN (1) or failed QP (4) on either side; solved ones must agree exactly
+        same = (st == out["status"]) | (np.isin(st, (1, 4)) & np.isin(out["status"], (1, 4)))
+        assert same.mean() >= 0.95, (it, st, out["status"])
+        ok = (st == 0) & (out["status"] == 0)
+        assert ok.sum() >= (0.3 * B if model == "fdyn6" else 0.8 * B), (it, np.bincount(st, minlength=5))
+        for t in range(len(plans)):      # every track contributes solved instances
+            assert (ok & (tid == t)).sum() >= 1, (names[t], st[tid == t])
+        assert _rel(s.get_x()[ok], x[ok]) < 1e-6 and _rel(s.get_u()[ok], u[ok]) < 1e-6      # tolerance 1e-6 relative
+        if it == 0:      # identical inputs on both sides (afterwards the iterates agree to 1e-6 only and the residuals cancel digits)
+            assert _rel(s.get_residuals()[same], out["res"][same]) < 1e-7
+        # keep the two sides together where only one of them failed
+        bad = ~ok
+        if bad.any():
+            xg, ug = s.get_x(), s.get_u()
+            x[bad], u[bad] = xg[bad], ug[bad]
+            pg, lg = s.get_multipliers()
+            pi[bad], lam[bad] = pg[bad], lg[bad]
+            s.set_x(x); s.set_u(u); s.set_multipliers(pi, lam)
+
+
+def _check_iterate(solver, ocp, B, frac_ok):
+    st = solver.get_status()
+    ok = st == 0
+    assert ok.mean() >= frac_ok, np.bincount(st, minlength=5)
+    x, u = solver.get_x(), solver.get_u()
+    assert np.all(np.isfinite(x[ok])) and np.all(np.isfinite(u[ok]))
+    c = ocp.constraints
+    tol = 1e-6
+    # hard boxes hold at the new iterate (the QP step is feasible for the linear rows; x_0 is the measured state)
+    for i, lo, hi in zip(c.idxbx, c.lbx, c.ubx):
+        assert np.all(x[ok][:, 1:-1, i] >= lo - tol * (1 + abs(lo))) and np.all(x[ok][:, 1:-1, i] <= hi + tol * (1 + abs(hi))), i
+    for i, lo, hi in zip(c.idxbu, c.lbu, c.ubu):
+        assert np.all(u[ok][:, :, i] >= lo - tol * (1 + abs(lo))) and np.all(u[ok][:, :, i] <= hi + tol * (1 + abs(hi))), i
+    g = u[ok] - x[ok][:, :-1, 6:8]                       # rate rows C x + D u (python/mpc.py:92-99)
+    assert np.all(g >= c.lg - tol * (1 + np.abs(c.lg))) and np.all(g <= c.ug + tol * (1 + np.abs(c.ug)))
+    res = solver.get_residuals()[ok]                      # NLP KKT inf-norms at the iterate the QP was built at
+    assert np.all(np.isfinite(res))
+    return ok
+
+
+def test_config1_full_size_properties(track):
+    """configs[1] at full size (B = 1024 kinematic, N = 40): 10 control steps in the persistent loop; every instance solves,
+    bounds hold, the dynamics defect of the iterate shrinks to the linearisation error, residuals are finite."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = 1024
+    ocp = make_ocp()
+    s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    x0 = sample_x0(track, B)
+    s.set_x0(x0); s.init_guess(); s.set_lap_wrap(True)
+    s.step(40.0, model=0, M_sim=25)
+    h = s.run_steps(40.0, 10, model=0, M_sim=25, u0_hist=True, status_hist=True, qp_iter_hist=True)
+    assert np.all(h["status"] == 0)
+    assert np.all(np.abs(h["u0"][..., 0]) <= 500.0 * (1 + 1e-9)) and np.all(np.abs(h["u0"][..., 1]) <= 0.5 * (1 + 1e-9))
+    assert 5 <= h["qp_iter"].mean() <= 15
+    _check_iterate(s, ocp, B, 1.0)
+    res = s.get_residuals()
+    assert res[:, 1].max() < 1e-1                        # dynamics defect after 11 RTI steps: the linearisation error only
+
+
+@pytest.mark.parametrize("model,frac", [("fdyn6u", 0.85), ("fdyn6", 0.03)])
+def test_config2_full_size_properties(track, model, frac):
+    """configs[2] at full size (B = 8192 dynamic bicycle + soft nonlinear track rows): 3 control steps with launches per step.
+    The model as written (quirk Q3) is open-loop unstable: most of its QPs fail (reported), the solved ones
+    must still satisfy the properties; the un-crossed model solves the bulk."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    B = 8192
+    ocp = make_ocp(model=model)
+    ocp.model.con_h_expr = "track"
+    c = ocp.constraints
+    c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+    c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+    ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+    ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+    widths = np.array([[track.right_widths.min(), track.left_widths.min()]])
+    s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, track_widths=widths)
+    x0 = sample_x0(track, B)
+    s.set_x0(x0); s.init_guess()
+    yref = np.zeros((B, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+    s.set_yref(yref); s.set_yref_e(yref_e); s.solve(3)
+    plant = {"fdyn6": 1, "fdyn6u": 2}[model]
+    for _ in range(3):
+        s.step(40.0, model=plant, M_sim=25)
+        s.synchronize()
+    ok = _check_iterate(s, ocp, B, frac)
+    slk = s.get_slacks()
+    assert np.all(slk[ok] >= 0.0) and np.all(np.isfinite(slk[ok]))
