@@ -24,6 +24,7 @@ class Config(C.Structure):
         ("nlp_solver_type", C.c_int32), ("nlp_solver_max_iter", C.c_int32), ("ipm_iter_max", C.c_int32),
         ("dt", C.c_double), ("cost_scale_stage", C.c_double), ("ipm_tol", C.c_double),
         ("ipm_mu0", C.c_double), ("ipm_tau0", C.c_double), ("nlp_tol", C.c_double),
+        ("integrator_type", C.c_int32), ("sim_integrator_type", C.c_int32),
     ]
 
 

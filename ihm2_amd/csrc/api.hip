@@ -122,7 +122,14 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     if (cfg->batch < 1) return fail("batch must be >= 1");
     if (cfg->N < 2 || cfg->N > IHM2MPC_NMAX) return fail("N must be in [2, %d]", IHM2MPC_NMAX);
     if (cfg->M < 1) return fail("M must be >= 1");
-    if (rk4_unstable(cfg->dt, cfg->M))
+    if (cfg->integrator_type < IHM2MPC_INTEG_ERK || cfg->integrator_type > IHM2MPC_INTEG_IRK_RADAU4 || cfg->sim_integrator_type < IHM2MPC_INTEG_ERK ||
+        cfg->sim_integrator_type > IHM2MPC_INTEG_IRK_RADAU4)
+        return fail("unknown integrator type (%d, %d)", cfg->integrator_type, cfg->sim_integrator_type);
+    if (cfg->integrator_type != IHM2MPC_INTEG_ERK && cfg->M != 1)
+        return fail("the IRK integrator of the shooting intervals takes one step per interval (sim_method_num_steps = 1, python/main.py:236); M = %d", cfg->M);
+    if (cfg->integrator_type != IHM2MPC_INTEG_ERK && cfg->nlp_solver_type == IHM2MPC_SQP)
+        return fail("the merit line search of the SQP mode integrates with RK4 only: use SQP_RTI with the IRK integrator");
+    if (cfg->integrator_type == IHM2MPC_INTEG_ERK && rk4_unstable(cfg->dt, cfg->M))
         return fail("RK4 with %d sub-step(s) of dt = %g is unstable on the actuator lags (t_T = 1e-3 s, t_delta = 0.02 s: |z| = dt / (M t) must stay "
                     "below 2.78): use M >= %d (the reference's sim_method_num_steps = 1 belongs to its IRK integrator, python/main.py:234-236)",
                     cfg->M, cfg->dt, (int)ceil(cfg->dt / (2.78 * 1e-3)));
@@ -723,7 +730,7 @@ int ihm2mpc_sim_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, const doub
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (!x || !u || !x_next) return fail("null argument");
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
+    if (h->cfg.sim_integrator_type == IHM2MPC_INTEG_ERK && rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     double *xs = h->scratch, *us = h->scratch + (size_t)h->B * 8, *xn = h->scratch + (size_t)h->B * 16;
     if (upload(h, x, xs, NX) || upload(h, u, us, NU)) return -1;
@@ -737,7 +744,7 @@ int ihm2mpc_sim_advance(ihm2mpc_handle *h, int32_t model, int32_t M_sim)
     CHECK_H(h);
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
+    if (h->cfg.sim_integrator_type == IHM2MPC_INTEG_ERK && rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     ihm2_launch_sim(h, model, M_sim, h->x0, h->u0, h->x0, h->stream, h->active_set ? h->active : nullptr);
     HIP_TRY(hipGetLastError());
@@ -807,7 +814,7 @@ int ihm2mpc_step(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_targe
     CHECK_H(h);
     if (ready(h)) return -1;
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
+    if (h->cfg.sim_integrator_type == IHM2MPC_INTEG_ERK && rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     // The plant step and the reference ramp only feed the QP (through x0 and yref); the warm-start shift and the
     // linearisation only need the previous iterate.  Two branches, joined in front of the QP kernel.
@@ -857,7 +864,7 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
     CHECK_H(h);
     if (ready(h)) return -1;
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
+    if (h->cfg.sim_integrator_type == IHM2MPC_INTEG_ERK && rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the actuator lags: use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (model < -2 || model > IHM2MPC_MODEL_FDYN6U) return fail("unknown plant model %d", model);
     if (n_steps < 1) return fail("n_steps must be >= 1");
     const size_t B = h->B, n = n_steps;

@@ -117,6 +117,10 @@ void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream
 void ihm2_launch_wrap_lap(ihm2mpc_handle *h);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);
+// kernels_irk.hip: the collocation integrators (cfg.integrator_type / cfg.sim_integrator_type != IHM2MPC_INTEG_ERK)
+void ihm2_launch_linearize_irk(ihm2mpc_handle *h);
+void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,
+                         const int32_t *active);
 void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last);
 int ihm2_launch_qp(ihm2mpc_handle *h);
 // the persistent per-instance loop (kernels_qp.hip); returns 1 if the configuration has no instantiation of it

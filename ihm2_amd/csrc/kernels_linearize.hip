@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64) void k_sim_step_kin(int B, int M, double dt, in
 
 void ihm2_launch_linearize(ihm2mpc_handle *h)
 {
+    if (h->cfg.integrator_type != IHM2MPC_INTEG_ERK) { ihm2_launch_linearize_irk(h); return; }
     const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U)
@@ -232,6 +233,7 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
 
 void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)
 {
+    if (h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK) { ihm2_launch_sim_irk(h, model, M_sim, x, u, xn, stream, active); return; }
     const int blocks = (h->B + 63) / 64;
     if (model == IHM2MPC_MODEL_FKIN6)
         hipLaunchKernelGGL(k_sim_step_kin, dim3(blocks), dim3(64), 0, stream, h->B, M_sim, h->cfg.dt, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id,

@@ -967,6 +967,7 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
 #endif
 {
     if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return 1;
+    if (h->cfg.integrator_type != IHM2MPC_INTEG_ERK || h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK) return 1;      // the loop integrates with RK4
     const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
     if (sqp && !h->ls_x) return 1;        // the caller allocates the line-search buffers first
     const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8;

@@ -22,6 +22,21 @@ MODEL_FDYN6 = 1
 MODEL_FDYN6U = 2     # fdyn6 with un-crossed slip angles (include/ihm2mpc.h: IHM2MPC_MODEL_FDYN6U); not in the reference
 _MODEL_IDS = {"fkin6": MODEL_FKIN6, "fdyn6": MODEL_FDYN6, "fdyn6u": MODEL_FDYN6U}
 INTEG_RK4 = 0
+INTEG_IRK_GL4 = 1      # IRK, GAUSS_LEGENDRE, 4 stages: acados' default collocation (python/main.py:234-236)
+INTEG_IRK_RADAU4 = 2   # IRK, GAUSS_RADAU_IIA, 4 stages (python/main.py:395-400, python/sim.py:28-33)
+
+
+def integrator_code(integrator_type: str, collocation_type: str = "GAUSS_LEGENDRE") -> int:
+    """``AcadosOcpOptions.integrator_type`` / ``AcadosSimOpts.integrator_type`` + ``collocation_type`` -> ``IHM2MPC_INTEG_*``."""
+    if integrator_type == "ERK":
+        return INTEG_RK4
+    if integrator_type == "IRK":
+        if collocation_type == "GAUSS_LEGENDRE":
+            return INTEG_IRK_GL4
+        if collocation_type == "GAUSS_RADAU_IIA":
+            return INTEG_IRK_RADAU4
+        raise ValueError(f"collocation_type {collocation_type!r}: GAUSS_LEGENDRE or GAUSS_RADAU_IIA")
+    raise ValueError(f"integrator_type {integrator_type!r}: ERK or IRK")
 
 
 @dataclass
@@ -169,7 +184,11 @@ class AcadosOcpOptions:
     nlp_solver_max_iter: int = 1
     hessian_approx: str = "GAUSS_NEWTON"
     hpipm_mode: str = "SPEED_ABS"
-    integrator_type: str = "ERK"                  # RK4 x sim_method_num_steps (old/generate.py:23-25)
+    integrator_type: str = "ERK"                  # "ERK": RK4 x sim_method_num_steps (old/generate.py:23-25); "IRK": 4-stage collocation, one step
+                                                  # per interval, 3 Newton iterations (python/main.py:234-236)
+    collocation_type: str = "GAUSS_LEGENDRE"      # IRK only (acados' default); or "GAUSS_RADAU_IIA"
+    sim_integrator_type: str = "ERK"              # integrator of the plant steps behind this solver (python/main.py:395-400: "IRK")
+    sim_collocation_type: str = "GAUSS_RADAU_IIA"
     sim_method_num_stages: int = 4
     sim_method_num_steps: int = 25                # M; 1 is unstable on this model
     globalization: str = "FIXED_STEP"             # or "MERIT_BACKTRACKING" (python/main.py:237); SQP mode only
@@ -272,6 +291,7 @@ class OcpData:
     dt: float
     model: int
     integrator: int
+    sim_integrator: int
     cost_scale_stage: float
     W: np.ndarray      # (N,12,12)
     W_e: np.ndarray    # (8,8)
@@ -317,10 +337,12 @@ class OcpData:
         if not (np.array_equal(ocp.cost.Vx, ref.cost.Vx) and np.array_equal(ocp.cost.Vu, ref.cost.Vu)
                 and np.array_equal(ocp.cost.Vx_e, np.eye(NX))):
             raise ValueError("output selectors Vx, Vu, Vx_e are fixed to those of python/mpc.py:51-64")
-        if o.integrator_type != "ERK":
-            raise ValueError("integrator_type must be 'ERK' (RK4 x sim_method_num_steps); IRK is not implemented")
+        integ = integrator_code(o.integrator_type, o.collocation_type)
+        sim_integ = integrator_code(o.sim_integrator_type, o.sim_collocation_type)
         if o.sim_method_num_stages != 4:
-            raise ValueError("ERK is the classical 4-stage RK4")
+            raise ValueError("4 stages: the classical RK4 (ERK) or 4-stage collocation (IRK), python/main.py:235")
+        if integ != INTEG_RK4 and o.sim_method_num_steps != 1:
+            raise ValueError("IRK takes one step per shooting interval (sim_method_num_steps = 1, python/main.py:236)")
         if o.nlp_solver_type not in ("SQP_RTI", "SQP"):
             raise ValueError(f"nlp_solver_type {o.nlp_solver_type!r}")
         if o.globalization not in ("FIXED_STEP", "MERIT_BACKTRACKING"):
@@ -387,7 +409,7 @@ class OcpData:
             soft_z=soft_z, soft_Z=soft_Z, path_on=path_on, car_L=float(ocp.model.car_length), car_W=float(ocp.model.car_width),
             lh=lh, uh=uh,
             N=N, M=int(o.sim_method_num_steps), dt=dt, model=ocp.model.model_id,
-            integrator=INTEG_RK4,
+            integrator=integ, sim_integrator=sim_integ,
             cost_scale_stage=dt if o.cost_scale_stage is None else float(o.cost_scale_stage),
             W=np.tile(np.asarray(ocp.cost.W, dtype=float)[None], (N, 1, 1)), W_e=np.array(ocp.cost.W_e, dtype=float),
             lbx=lbx, ubx=ubx, lbu=lbu, ubu=ubu,

@@ -56,7 +56,7 @@ class BatchedOcpSolver:
             batch=self.B, N=d.N, M=d.M, model=d.model, ntracks=self.ntracks, nknots=self.nknots, device=device,
             nlp_solver_type=_SOLVER_TYPE[d.nlp_solver_type], nlp_solver_max_iter=d.nlp_solver_max_iter,
             ipm_iter_max=d.ipm_iter_max, dt=d.dt, cost_scale_stage=d.cost_scale_stage, ipm_tol=d.ipm_tol,
-            ipm_mu0=d.ipm_mu0, ipm_tau0=d.ipm_tau0, nlp_tol=d.nlp_tol)
+            ipm_mu0=d.ipm_mu0, ipm_tau0=d.ipm_tau0, nlp_tol=d.nlp_tol, integrator_type=d.integrator, sim_integrator_type=d.sim_integrator)
         self._h = C.c_void_p()
         _lib.check(self.lib.ihm2mpc_create(C.byref(cfg), C.byref(self._h)))
         self._s_ref, self._kappa_ref = s_ref.copy(), kappa_ref.copy()

@@ -71,12 +71,22 @@ extern "C" {
 #define IHM2MPC_FIXED_STEP 0         /* full steps */
 #define IHM2MPC_MERIT_BACKTRACKING 1 /* python/main.py:237 */
 
+/* integrators (AcadosOcpOptions.integrator_type / collocation_type, AcadosSimOpts): ERK = classical RK4 x M sub-steps; IRK = 4-stage
+ * collocation x M steps, 3 Newton iterations per step from K = 0 with a fresh Jacobian each (acados' defaults), forward
+ * sensitivities by the implicit-function theorem; GL4 = GAUSS_LEGENDRE (acados' default, python/main.py:234-236), RADAU4 =
+ * GAUSS_RADAU_IIA (python/main.py:395-400, python/sim.py:28-33) */
+#define IHM2MPC_INTEG_ERK 0
+#define IHM2MPC_INTEG_IRK_GL4 1
+#define IHM2MPC_INTEG_IRK_RADAU4 2
+#define IHM2MPC_IRK_NEWTON_ITER 3
+
 typedef struct ihm2mpc_handle ihm2mpc_handle;
 
 typedef struct ihm2mpc_config {
     int32_t batch;          /* B: independent MPC instances on this device */
     int32_t N;              /* shooting intervals (python/main.py:183: Nf = 40) */
-    int32_t M;              /* RK4 sub-steps per interval (sim_method_num_steps); >= 20 for stability */
+    int32_t M;              /* integrator steps per interval (sim_method_num_steps): RK4 sub-steps, >= 18 at dt = 0.05 for stability (ERK);
+                             * 1 for IRK (python/main.py:236) */
     int32_t model;          /* IHM2MPC_MODEL_* of the OCP */
     int32_t ntracks;        /* number of track tables */
     int32_t nknots;         /* knots per table (python/motion_planning.py:25,402-428: 3*500) */
@@ -90,6 +100,8 @@ typedef struct ihm2mpc_config {
     double ipm_mu0;         /* initial barrier parameter factor */
     double ipm_tau0;        /* initial slack floor */
     double nlp_tol;         /* SQP mode: KKT tolerance */
+    int32_t integrator_type;     /* IHM2MPC_INTEG_* of the shooting intervals (python/main.py:234: "IRK"; old/generate.py:23: "ERK") */
+    int32_t sim_integrator_type; /* IHM2MPC_INTEG_* of the plant steps (python/main.py:395-400: IRK, GAUSS_RADAU_IIA, 4 stages) */
 } ihm2mpc_config;
 
 const char *ihm2mpc_last_error(void);

@@ -40,7 +40,12 @@ extern "C" {
  * quirk Q3), which makes the model open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s) */
 /* KIN6 / DYN6: the Cartesian plants of the ROS simulation node (python/models.py:168-229, 310-452), state (X, Y, phi, ...) */
 enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1, ORC_MODEL_FDYN6U = 2, ORC_MODEL_KIN6 = 3, ORC_MODEL_DYN6 = 4 };
-enum { ORC_INTEG_RK4 = 0 };
+/* ORC_INTEG_RK4: classical RK4 x M (acados ERK, 4 stages, num_steps = M; old/generate.py:23-25).
+ * ORC_INTEG_IRK_GL4 / _RADAU4: 4-stage collocation, M steps, 3 Newton iterations per step from K = 0 with a fresh Jacobian each (acados
+ * IRK defaults: sim_method_newton_iter 3, jac_reuse 0) -- python/main.py:234-236 (OCP: Gauss-Legendre, 1 step),
+ * python/main.py:395-400 (plants: Radau IIA, 100 steps); forward sensitivities by the implicit-function theorem at the final stage values */
+enum { ORC_INTEG_RK4 = 0, ORC_INTEG_IRK_GL4 = 1, ORC_INTEG_IRK_RADAU4 = 2 };
+#define ORC_IRK_NEWTON_ITER 3
 
 typedef struct {
     int N;       /* shooting intervals */
@@ -164,6 +169,9 @@ void orc_prepare_step(int N, int B, const double *x0, double s_target, double *x
                       double *yref, double *yref_e);
 
 /* plant step for closed-loop (python/main.py:476-502): RK4 x M on the chosen model */
+/* plant step with a chosen integrator (ORC_INTEG_*) */
+void orc_sim_step_integ(const orc_problem *P, int B, int model, int integrator, int M, const double *x, const double *u,
+                        const int *track_id, double *xnext, int nthreads);
 void orc_sim_step(const orc_problem *P, int B, int model, int M, const double *x, const double *u,
                   const int *track_id, double *xnext, int nthreads);
 

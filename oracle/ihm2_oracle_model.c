@@ -446,7 +446,7 @@ void orc_jac(int model, const double *x, const double *u, const double *s_ref, c
 /* ---- RK4 x M with forward sensitivities (internal numerical differentiation) ----
  * S = d x_m / d (x_0, u) (8x10), S_0 = [I 0]. Stage i: X_i = x + a_i h K_{i-1},
  * dX_i = S + a_i h dK_{i-1}, dK_i = Jx(X_i) dX_i + [0 | Ju(X_i)].
- * `integrator` is reserved (only ORC_INTEG_RK4 exists). */
+ * integrator = ORC_INTEG_RK4; the collocation integrators are irk_core below. */
 static void stage_eval(int model, int with_sens, const double *X, const double *u, const double *s_ref, const double *kappa_ref, int nk,
                        const double *dX /*8x10*/, double *K, double *dK /*8x10*/)
 {
@@ -461,11 +461,114 @@ static void stage_eval(int model, int with_sens, const double *X, const double *
         }
 }
 
+#include "irk_tableaux.h"
+
+/* dense LU with partial pivoting, in place; returns 0 if singular */
+static int lu_factor(int n, double *Mx, int *piv)
+{
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++) if (fabs(Mx[r * n + c]) > fabs(Mx[p * n + c])) p = r;
+        piv[c] = p;
+        if (Mx[p * n + c] == 0.0) return 0;
+        if (p != c) for (int j = 0; j < n; j++) { double t = Mx[c * n + j]; Mx[c * n + j] = Mx[p * n + j]; Mx[p * n + j] = t; }
+        for (int r = c + 1; r < n; r++) {
+            const double l = Mx[r * n + c] / Mx[c * n + c];
+            Mx[r * n + c] = l;
+            for (int j = c + 1; j < n; j++) Mx[r * n + j] -= l * Mx[c * n + j];
+        }
+    }
+    return 1;
+}
+static void lu_solve(int n, const double *Mx, const int *piv, double *rhs, int nrhs)
+{
+    /* all row interchanges first (the stored multipliers were swapped along with later pivots), then L, then U */
+    for (int c = 0; c < n; c++)
+        if (piv[c] != c) for (int j = 0; j < nrhs; j++) { double t = rhs[c * nrhs + j]; rhs[c * nrhs + j] = rhs[piv[c] * nrhs + j]; rhs[piv[c] * nrhs + j] = t; }
+    for (int c = 0; c < n; c++)
+        for (int r = c + 1; r < n; r++) for (int j = 0; j < nrhs; j++) rhs[r * nrhs + j] -= Mx[r * n + c] * rhs[c * nrhs + j];
+    for (int c = n - 1; c >= 0; c--) {
+        for (int j = 0; j < nrhs; j++) rhs[c * nrhs + j] /= Mx[c * n + c];
+        for (int r = 0; r < c; r++) for (int j = 0; j < nrhs; j++) rhs[r * nrhs + j] -= Mx[r * n + c] * rhs[c * nrhs + j];
+    }
+}
+
+/* ---- 4-stage collocation (IRK) x M steps with forward sensitivities (acados IRK, python/main.py:234-236,395-400) ----
+ * Stage values K_i solve K_i = f(x + h sum_j A_ij K_j, u): ORC_IRK_NEWTON_ITER Newton iterations from K = 0, Jacobian
+ * I - h (A (x) J) re-evaluated in each (32 x 32, dense LU); x+ = x + h sum_i b_i K_i.  Sensitivities by the implicit-function
+ * theorem at the final stage values: (I - h A (x) J) dK = [J_x S + (0 | J_u)]_i, S+ = S + h sum_i b_i dK_i. */
+static void irk_core(int model, int integrator, int with_sens, const double *x0, const double *u, const double *s_ref, const double *kappa_ref, int nk,
+                     double dt, int M, double *xn, double *S)
+{
+    const double (*At)[4] = (integrator == ORC_INTEG_IRK_RADAU4) ? IRK_RADAU4_A : IRK_GL4_A;
+    const double *bt = (integrator == ORC_INTEG_IRK_RADAU4) ? IRK_RADAU4_b : IRK_GL4_b;
+    enum { NS4 = 4, NK = 4 * ORC_NX };
+    const double h = dt / M;
+    double x[ORC_NX];
+    memcpy(x, x0, sizeof x);
+    if (with_sens) {
+        memset(S, 0, sizeof(double) * ORC_NX * ORC_NZ);
+        for (int i = 0; i < ORC_NX; i++) S[i * ORC_NZ + i] = 1.0;
+    }
+    for (int m = 0; m < M; m++) {
+        double K[NS4][ORC_NX], F[NS4][ORC_NX], J[NS4][ORC_NX * ORC_NZ], Mx[NK * NK];
+        int piv[NK];
+        memset(K, 0, sizeof K);
+        for (int it = 0; it <= ORC_IRK_NEWTON_ITER; it++) {
+            const int last = it == ORC_IRK_NEWTON_ITER;      /* the last pass only evaluates the Jacobians the sensitivities need */
+            if (last && !with_sens) break;
+            for (int i = 0; i < NS4; i++) {
+                double X[ORC_NX];
+                for (int a = 0; a < ORC_NX; a++) {
+                    double acc = x[a];
+                    for (int j = 0; j < NS4; j++) acc += h * At[i][j] * K[j][a];
+                    X[a] = acc;
+                }
+                orc_jac(model, X, u, s_ref, kappa_ref, nk, F[i], J[i]);
+            }
+            for (int i = 0; i < NS4; i++)
+                for (int a = 0; a < ORC_NX; a++)
+                    for (int j = 0; j < NS4; j++)
+                        for (int b = 0; b < ORC_NX; b++)
+                            Mx[(i * ORC_NX + a) * NK + j * ORC_NX + b] = ((i == j && a == b) ? 1.0 : 0.0) - h * At[i][j] * J[i][a * ORC_NZ + b];
+            if (!lu_factor(NK, Mx, piv)) { for (int a = 0; a < ORC_NX; a++) x[a] = NAN; break; }
+            if (last) break;
+            double r[NK];
+            for (int i = 0; i < NS4; i++) for (int a = 0; a < ORC_NX; a++) r[i * ORC_NX + a] = -(K[i][a] - F[i][a]);
+            lu_solve(NK, Mx, piv, r, 1);
+            for (int i = 0; i < NS4; i++) for (int a = 0; a < ORC_NX; a++) K[i][a] += r[i * ORC_NX + a];
+        }
+        if (with_sens) {
+            double R[NK * ORC_NZ];
+            for (int i = 0; i < NS4; i++)
+                for (int a = 0; a < ORC_NX; a++)
+                    for (int c = 0; c < ORC_NZ; c++) {
+                        double acc = (c >= ORC_NX) ? J[i][a * ORC_NZ + c] : 0.0;
+                        for (int l = 0; l < ORC_NX; l++) acc += J[i][a * ORC_NZ + l] * S[l * ORC_NZ + c];
+                        R[(i * ORC_NX + a) * ORC_NZ + c] = acc;
+                    }
+            lu_solve(NK, Mx, piv, R, ORC_NZ);
+            for (int a = 0; a < ORC_NX; a++)
+                for (int c = 0; c < ORC_NZ; c++) {
+                    double acc = S[a * ORC_NZ + c];
+                    for (int i = 0; i < NS4; i++) acc += h * bt[i] * R[(i * ORC_NX + a) * ORC_NZ + c];
+                    S[a * ORC_NZ + c] = acc;
+                }
+        }
+        for (int a = 0; a < ORC_NX; a++) {
+            double acc = x[a];
+            for (int i = 0; i < NS4; i++) acc += h * bt[i] * K[i][a];
+            x[a] = acc;
+        }
+    }
+    memcpy(xn, x, sizeof x);
+}
+
 static void rk4_core(int model, int integrator, int with_sens, const double *x0, const double *u, const double *s_ref, const double *kappa_ref, int nk,
                      double dt, int M, double *xn, double *S)
 {
+    if (integrator != ORC_INTEG_RK4) { irk_core(model, integrator, with_sens, x0, u, s_ref, kappa_ref, nk, dt, M, xn, S); return; }
     const double h = dt / M;
-    (void)integrator;
     static const double a[4] = {0.0, 0.5, 0.5, 1.0};
     static const double w[4] = {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0};
     double x[ORC_NX];

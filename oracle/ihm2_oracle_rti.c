@@ -507,13 +507,19 @@ void orc_prepare_step(int N, int B, const double *x0, double s_target, double *x
 void orc_sim_step(const orc_problem *P, int B, int model, int M, const double *x, const double *u,
                   const int *track_id, double *xnext, int nthreads)
 {
+    orc_sim_step_integ(P, B, model, ORC_INTEG_RK4, M, x, u, track_id, xnext, nthreads);
+}
+
+void orc_sim_step_integ(const orc_problem *P, int B, int model, int integrator, int M, const double *x, const double *u,
+                        const int *track_id, double *xnext, int nthreads)
+{
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #pragma omp parallel for schedule(static) num_threads(nthreads)
 #endif
     for (int i = 0; i < B; i++) {
         int tid = track_id ? track_id[i] : 0;
-        orc_rk4(model, ORC_INTEG_RK4, x + (size_t)i * NX, u + (size_t)i * NU, track_s(P, tid), track_k(P, tid),
+        orc_rk4(model, integrator, x + (size_t)i * NX, u + (size_t)i * NU, track_s(P, tid), track_k(P, tid),
                 P->nknots, P->dt, M, xnext + (size_t)i * NX);
     }
 }

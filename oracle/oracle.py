@@ -16,6 +16,8 @@ _LIB_PATH = os.path.join(_HERE, "libihm2_oracle.so")
 NX, NU, NZ, NY, NC, NG, NH = 8, 2, 10, 12, 14, 2, 2
 MODEL_FKIN6, MODEL_FDYN6, MODEL_FDYN6U, MODEL_KIN6, MODEL_DYN6 = 0, 1, 2, 3, 4
 INTEG_RK4 = 0
+INTEG_IRK_GL4 = 1      # acados IRK, GAUSS_LEGENDRE, 4 stages (python/main.py:234-236)
+INTEG_IRK_RADAU4 = 2   # acados IRK, GAUSS_RADAU_IIA, 4 stages (python/main.py:395-400, python/sim.py:28-33)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -257,12 +259,13 @@ class OracleProblem:
         lib().orc_build_qp(C.byref(self.p), xp, up, x0p, yp, yep, C.c_int(track_id), *[a.ctypes.data_as(_dp) for a in (H, g, A, Bm, b, dx0, R, dl, du)])
         return dict(H=H, g=g, A=A, Bm=Bm, b=b, dx0=dx0, R=R, dl=dl, du=du)
 
-    def sim_step(self, x, u, model, M, track_id=None, nthreads=0):
+    def sim_step(self, x, u, model, M, track_id=None, nthreads=0, integrator=INTEG_RK4):
         B = x.shape[0]
         x, xp = _d(x); u, up = _d(u)
         tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
         xn = np.zeros((B, NX))
-        lib().orc_sim_step(C.byref(self.p), C.c_int(B), C.c_int(model), C.c_int(M), xp, up, tp, xn.ctypes.data_as(_dp), C.c_int(nthreads))
+        lib().orc_sim_step_integ(C.byref(self.p), C.c_int(B), C.c_int(model), C.c_int(integrator), C.c_int(M), xp, up, tp, xn.ctypes.data_as(_dp),
+                                 C.c_int(nthreads))
         return xn
 
 
