@@ -71,6 +71,8 @@ __device__ __forceinline__ double quad_get(double v, int j)      // j is a compi
 template <int NR>
 __device__ __forceinline__ void quad_solve12(const int st, double (&Mr)[3][12], double (&R)[3][NR])
 {
+    // (inner loops over all 12 columns with the condition c > p inside: trip counts that depend on p kept the compiler from
+    // unrolling them, and the matrix went to scratch memory)
 #pragma unroll
     for (int p = 0; p < 12; p++) {
         const int pj = p / 3, pb = p % 3;                 // the pivot row: local row pb of the lane that owns stage pj
@@ -78,7 +80,7 @@ __device__ __forceinline__ void quad_solve12(const int st, double (&Mr)[3][12], 
         const double ipiv = 1.0 / quad_get(Mr[pb][p], pj);
         double prow[12], prhs[NR];
 #pragma unroll
-        for (int c = p + 1; c < 12; c++) prow[c] = quad_get(Mr[pb][c], pj) * ipiv;
+        for (int c = 0; c < 12; c++) prow[c] = (c > p) ? quad_get(Mr[pb][c], pj) * ipiv : 0.0;
 #pragma unroll
         for (int c = 0; c < NR; c++) prhs[c] = quad_get(R[pb][c], pj) * ipiv;
 #pragma unroll
@@ -86,20 +88,26 @@ __device__ __forceinline__ void quad_solve12(const int st, double (&Mr)[3][12], 
             const bool is_piv = owner && r == pb;
             const double f = is_piv ? 0.0 : Mr[r][p];
 #pragma unroll
-            for (int c = p + 1; c < 12; c++) Mr[r][c] = is_piv ? prow[c] : fma(-f, prow[c], Mr[r][c]);
+            for (int c = 0; c < 12; c++)
+                if (c > p) Mr[r][c] = is_piv ? prow[c] : fma(-f, prow[c], Mr[r][c]);
 #pragma unroll
             for (int c = 0; c < NR; c++) R[r][c] = is_piv ? prhs[c] : fma(-f, prhs[c], R[r][c]);
         }
     }
 }
 
+// structural non-zeros of the model Jacobian (model.hpp: JX_MASK / JU_MASK): with constant indices the test folds at compile time, so
+// the zero entries cost neither arithmetic nor registers (80 Jacobian entries per lane do not fit beside the 12 x 12 block)
+template <int MODEL>
+__device__ __forceinline__ constexpr bool jnz(int a, int c)
+{
+    return (c < 8) ? ((JX_MASK[MODEL ? 1 : 0][a] >> c) & 1u) != 0 : ((JU_MASK[MODEL ? 1 : 0][a] >> (c - 8)) & 1u) != 0;
+}
+
 template <int MODEL>
 __device__ __forceinline__ void eval_model(const double (&X)[8], double u_T, double u_d, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
 {
-#pragma unroll
-    for (int a = 0; a < 8; a++)
-#pragma unroll
-        for (int c = 0; c < 10; c++) J[a][c] = 0.0;
+    // (structural zeros of J are never written and never read: jnz)
     if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, f, J);
     else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, f, J);
 }
@@ -159,13 +167,16 @@ __device__ __forceinline__ void irk_step(const int st, const IrkRows &tab, const
                 for (int j = 0; j < 4; j++) {
                     double cpl = 0.0;      // J[a][solved unknowns] . step of stage j
 #pragma unroll
-                    for (int q = 0; q < 2; q++) cpl = fma(J[a][G1(q)], quad_get(d[G1(q)], j), cpl);
+                    for (int q = 0; q < 2; q++) if (jnz<MODEL>(a, G1(q))) cpl = fma(J[a][G1(q)], quad_get(d[G1(q)], j), cpl);
                     if (grp)
 #pragma unroll
-                        for (int q = 0; q < 3; q++) cpl = fma(J[a][G2(q)], quad_get(d[G2(q)], j), cpl);
+                        for (int q = 0; q < 3; q++) if (jnz<MODEL>(a, G2(q))) cpl = fma(J[a][G2(q)], quad_get(d[G2(q)], j), cpl);
                     rhs = fma(h * Arow[j], cpl, rhs);
 #pragma unroll
-                    for (int bq = 0; bq < 3; bq++) Mr[r][3 * j + bq] = ((j == st && bq == r) ? 1.0 : 0.0) - h * Arow[j] * J[a][grp ? G3(bq) : G2(bq)];
+                    for (int bq = 0; bq < 3; bq++) {
+                        const double unit = (j == st && bq == r) ? 1.0 : 0.0;
+                        Mr[r][3 * j + bq] = jnz<MODEL>(a, grp ? G3(bq) : G2(bq)) ? unit - h * Arow[j] * J[a][grp ? G3(bq) : G2(bq)] : unit;
+                    }
                 }
                 R[r][0] = rhs;
             }
@@ -180,7 +191,7 @@ __device__ __forceinline__ void irk_step(const int st, const IrkRows &tab, const
 
 // Sensitivity columns COL0 .. COL0 + NCOL - 1 of one collocation step that starts from S = [I 0] (the first and, for the reference's
 // sim_method_num_steps = 1, only step): (I - h A (x) J) dK = [J_x | J_u], J at the final stage values.  dK[a][c]: this lane's stage.
-template <int COL0, int NCOL>
+template <int MODEL, int COL0, int NCOL>
 __device__ __forceinline__ void irk_sens_cols(const int st, const IrkRows &tab, const double (&J)[8][10], double (&dK)[8][NCOL])
 {
     const double h = tab.h;
@@ -191,8 +202,9 @@ __device__ __forceinline__ void irk_sens_cols(const int st, const IrkRows &tab, 
 #pragma unroll
         for (int c = 0; c < NCOL; c++) {
             double acc = 0.0;
+            if (jnz<MODEL>(a, COL0 + c))
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc = fma((a == 6) ? invT[j] : invD[j], quad_get(J[a][COL0 + c], j), acc);
+                for (int j = 0; j < 4; j++) acc = fma((a == 6) ? invT[j] : invD[j], quad_get(J[a][COL0 + c], j), acc);
             dK[a][c] = acc;
         }
     }
@@ -203,21 +215,24 @@ __device__ __forceinline__ void irk_sens_cols(const int st, const IrkRows &tab, 
         for (int r = 0; r < 3; r++) {
             const int a = grp ? G3(r) : G2(r);
 #pragma unroll
-            for (int c = 0; c < NCOL; c++) R[r][c] = J[a][COL0 + c];
+            for (int c = 0; c < NCOL; c++) R[r][c] = jnz<MODEL>(a, COL0 + c) ? J[a][COL0 + c] : 0.0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
 #pragma unroll
                 for (int c = 0; c < NCOL; c++) {
                     double cpl = 0.0;
 #pragma unroll
-                    for (int q = 0; q < 2; q++) cpl = fma(J[a][G1(q)], quad_get(dK[G1(q)][c], j), cpl);
+                    for (int q = 0; q < 2; q++) if (jnz<MODEL>(a, G1(q))) cpl = fma(J[a][G1(q)], quad_get(dK[G1(q)][c], j), cpl);
                     if (grp)
 #pragma unroll
-                        for (int q = 0; q < 3; q++) cpl = fma(J[a][G2(q)], quad_get(dK[G2(q)][c], j), cpl);
+                        for (int q = 0; q < 3; q++) if (jnz<MODEL>(a, G2(q))) cpl = fma(J[a][G2(q)], quad_get(dK[G2(q)][c], j), cpl);
                     R[r][c] = fma(h * Arow[j], cpl, R[r][c]);
                 }
 #pragma unroll
-                for (int bq = 0; bq < 3; bq++) Mr[r][3 * j + bq] = ((j == st && bq == r) ? 1.0 : 0.0) - h * Arow[j] * J[a][grp ? G3(bq) : G2(bq)];
+                for (int bq = 0; bq < 3; bq++) {
+                    const double unit = (j == st && bq == r) ? 1.0 : 0.0;
+                    Mr[r][3 * j + bq] = jnz<MODEL>(a, grp ? G3(bq) : G2(bq)) ? unit - h * Arow[j] * J[a][grp ? G3(bq) : G2(bq)] : unit;
+                }
             }
         }
         quad_solve12<NCOL>(st, Mr, R);
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(64) void k_linearize_irk(int B, int N, int M, IrkTa
     double *rec = lin + ((size_t)b * N + k) * LIN_REC;
     {
         double dK[8][5];
-        irk_sens_cols<0, 5>(st, rows, J, dK);
+        irk_sens_cols<MODEL, 0, 5>(st, rows, J, dK);
 #pragma unroll
         for (int a = 0; a < 8; a++)
 #pragma unroll
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(64) void k_linearize_irk(int B, int N, int M, IrkTa
     }
     {
         double dK[8][5];
-        irk_sens_cols<5, 5>(st, rows, J, dK);
+        irk_sens_cols<MODEL, 5, 5>(st, rows, J, dK);
 #pragma unroll
         for (int a = 0; a < 8; a++)
 #pragma unroll

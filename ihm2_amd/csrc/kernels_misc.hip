@@ -112,8 +112,11 @@ void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed)
 {
     const int32_t *mask = only_failed ? h->status : nullptr;
+    // the rollout is an RK4 rollout whatever the OCP's integrator: with IRK (one step per interval) it takes the 25 sub-steps RK4 needs
+    // on the actuator lags (a guess: the first linearisation sees its defects against the OCP's own discretisation)
+    const int M_roll = (h->cfg.integrator_type == IHM2MPC_INTEG_ERK) ? h->cfg.M : 25;
 #define LAUNCH_IG(MD)                                                                                                          \
-    hipLaunchKernelGGL(k_init_guess<MD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,      \
+    hipLaunchKernelGGL(k_init_guess<MD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, M_roll, h->cfg.dt,      \
                        v_ref_scale, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x0, h->lbu, h->ubu, h->lg, h->ug,    \
                        h->x, h->u, mask, h->pi, h->lam)
     // recovery of a few failed instances: the kinematic rollout is 5x cheaper and its defects are what one RTI step absorbs
