@@ -111,3 +111,48 @@ def test_irk_needs_a_fraction_of_the_rk4_work(track):
         s.free()
     print("linearisation of 1024 x 40 intervals [ms]:", t)
     assert t["IRK GL4x1"] < t["RK4x25"]
+
+
+def test_sim_solver_object_replays_the_reference_plant_calls(track):
+    """``generate_sim_solver`` + ``AcadosSimSolver.set / solve / get / simulate`` as ``python/main.py:395-435,476-502`` use them:
+    three plant objects (fkin6, fdyn6, fdyn6u) with the reference's options, ``p`` set afterwards, the model switch of the loop."""
+    from ihm2_amd import ocp as O
+    from ihm2_amd.constants import l_R
+    from ihm2_amd.sim import AcadosSimOpts, generate_sim_solver
+    from oracle import oracle as orc
+
+    dt = 0.05
+    sim_opts = AcadosSimOpts()
+    sim_opts.T = dt; sim_opts.num_stages = 4; sim_opts.num_steps = 100
+    sim_opts.integrator_type = "IRK"; sim_opts.collocation_type = "GAUSS_RADAU_IIA"
+    model = O.get_acados_model_from_explicit_dynamics("ihm2_fkin6", O.fkin6_model, 8, 2, 3000)
+    model_fdyn6 = O.get_acados_model_from_implicit_dynamics("fdyn6", O.fdyn6u_model, 8, 2, 3000)
+    sim_solver = generate_sim_solver(model, sim_opts, "generated", generate=True, build=True)
+    sim_solver_fdyn6 = generate_sim_solver(model_fdyn6, sim_opts, "generated", generate=True, build=True)
+    p = np.append(track.s_ref, track.kappa_ref)
+    sim_solver.set("p", p); sim_solver_fdyn6.set("p", p)
+    P = orc.OracleProblem(make_ocp().flatten().as_dict(track.s_ref, track.kappa_ref))
+    x = np.zeros(8); x[0] = -6.0                   # python/main.py:438-441
+    used = set()
+    for i in range(25):
+        u = np.array([400.0 if i < 18 else 100.0, 0.25 * np.sin(0.4 * i)])
+        beta = np.arctan(0.5 * np.tan(x[7]))
+        kin = (x[3] ** 2 + x[4] ** 2) * np.sin(beta) / l_R <= 3.0      # python/main.py:482-489
+        used.add(bool(kin))
+        solver = sim_solver if kin else sim_solver_fdyn6
+        xn = solver.simulate(x, u)
+        assert xn.shape == (8,) and solver.get("CPUtime") > 0.0
+        xo = P.sim_step(x[None], u[None], 0 if kin else 2, 100, integrator=orc.INTEG_IRK_RADAU4)[0]
+        assert _rel(xn, xo) < 1e-10, i
+        x = xn
+    assert used == {True, False}                   # both plants were exercised
+    # set / solve / get, batched
+    B = 33
+    sb = generate_sim_solver(model, sim_opts, "generated", batch_size=B)
+    sb.set("p", p); sb.set("T", dt)
+    xs = sample_x0(track, B, seed=9); us = np.stack([np.linspace(-100, 300, B), np.linspace(-0.2, 0.2, B)], 1)
+    sb.set("x", xs); sb.set("u", us)
+    assert sb.solve() == 0
+    assert _rel(sb.get("x"), P.sim_step(xs, us, 0, 100, integrator=orc.INTEG_IRK_RADAU4)) < 1e-10
+    for s_ in (sim_solver, sim_solver_fdyn6, sb):
+        s_.free()
