@@ -139,6 +139,12 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N>1 path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="barrier / max-reduce / final gather over the C ABI's own RCCL communicator (ihm2mpc_comm_*, no PyTorch) instead of "
+                         "torch.distributed; the RCCL id travels over a TCP socket on MASTER_ADDR")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="shard ONE global batch of this many instances over the ranks (contiguous block split, ihm2_amd/dist.py::shard_bounds: "
+                         "strong scaling, BASELINE.json configs[3] style) instead of --batch instances per rank")
     args = ap.parse_args()
     if args.lib:
         from ihm2_amd import _lib
@@ -153,7 +159,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1 or os.environ.get("IHM2_FORCE_DIST") == "1":      # the latter: rehearse the RCCL path on one GPU
+    use_dist = world > 1 or os.environ.get("IHM2_FORCE_DIST") == "1"      # the latter: rehearse the RCCL path on one GPU
+    native = None
+    if use_dist and not args.native_rccl:
         import torch
         import torch.distributed as dist
 
@@ -166,12 +174,26 @@ def main():
     from ihm2_amd.solver import BatchedOcpSolver
 
     B = args.batch
+    lo = 0
+    if args.global_batch:
+        from ihm2_amd.dist import shard_bounds
+
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        B = hi - lo
     ocp, track = build_problem(B)
     device = local_rank if args.device is None else args.device
     on_gpu = args.dist_backend == "nccl"
     solver = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, device=device)
-    x0 = sample_x0(track, B, seed=20240607 + rank)
+    if args.global_batch:      # one global Monte-Carlo batch, this rank's block of it
+        x0 = np.ascontiguousarray(sample_x0(track, args.global_batch, seed=20240607)[lo:lo + B])
+    else:
+        x0 = sample_x0(track, B, seed=20240607 + rank)
     solver.set_x0(x0)
+    if use_dist and args.native_rccl:
+        from ihm2_amd.dist import NativeComm
+
+        total = args.global_batch if args.global_batch else B * world
+        native = NativeComm(solver, total, world, rank, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 23)
     solver.init_guess()
     solver.set_lap_wrap(True)        # any number of steps: cars that complete a lap are moved back by one lap length
 
@@ -184,6 +206,8 @@ def main():
 
     def barrier():
         solver.synchronize()
+        if native is not None:
+            native.allreduce_max(0.0)
         if dist is not None:
             import torch
 
@@ -253,7 +277,13 @@ def main():
                 b1_ms.append((time.perf_counter() - ts) * 1e3)
         one.free()
 
-    if dist is not None:
+    if native is not None:
+        elapsed = native.allreduce_max(elapsed)
+        tg0 = time.perf_counter()
+        u0_all, status_all = native.allgather_results()      # RCCL all-gather of (u0, status) behind the C ABI, host copies on every rank
+        gather_ms = (time.perf_counter() - tg0) * 1e3
+        assert u0_all.shape == (native.total, 2)
+    elif dist is not None:
         import torch
 
         from ihm2_amd.dist import all_gather_blocks
@@ -282,7 +312,7 @@ def main():
         status_all = status
 
     if rank == 0:
-        total_solves = B * world * args.steps
+        total_solves = (args.global_batch if args.global_batch else B * world) * args.steps
         value = total_solves / elapsed
         n_ipm = float(np.mean(qp_iters))
         f_lin, f_qp = flops_per_solve(n_ipm)
@@ -314,12 +344,14 @@ def main():
         out = {
             "metric": "NMPC RTI solves/s (batch), N=40, nx=8 (6-DOF bicycle), fkin6",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: batch={B}/GPU kinematic bicycle fkin6, N=40, dt=0.05, RK4 x M={M_SUB}, "
                                    f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 read-back to pinned host memory; "
                                    + ("all steps in one launch, every instance on its own wavefront (ihm2mpc_run_steps)" if persistent else "one launch per phase and step (ihm2mpc_step)"),
-                       "batch_per_gpu": B, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards"},
+                       "batch_per_gpu": B, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards",
+                       "collective": ("RCCL all-gather of (u0, status) behind the C ABI (ihm2mpc_comm_*)" if native is not None else
+                                      "torch.distributed all_gather of (u0, status)" if dist is not None else "none (one GPU)")},
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes * B * (args.steps if persistent else 1),
@@ -347,6 +379,9 @@ def main():
             out["max_rel_dev_vs_oracle"] = max(chk["max_rel_dev_x"], chk["max_rel_dev_u"])
             out["oracle_check"] = chk
         print(json.dumps(out))
+    if native is not None:
+        native.allreduce_max(0.0)
+        native.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

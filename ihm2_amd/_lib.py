@@ -33,6 +33,14 @@ _H = C.c_void_p
 SYMBOLS = {
     "ihm2mpc_last_error": (C.c_char_p, []),
     "ihm2mpc_version": (C.c_char_p, []),
+    "ihm2mpc_group_create": (C.c_int, [C.POINTER(_H), C.c_int32, C.POINTER(_H)]),
+    "ihm2mpc_group_allgather_results": (C.c_int, [_H, c_double_p, c_int32_p]),
+    "ihm2mpc_group_free": (C.c_int, [_H]),
+    "ihm2mpc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "ihm2mpc_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), c_int32_p]),
+    "ihm2mpc_comm_allgather_results": (C.c_int, [_H, c_double_p, c_int32_p]),
+    "ihm2mpc_comm_allreduce_max": (C.c_int, [_H, c_double_p]),
+    "ihm2mpc_comm_free": (C.c_int, [_H]),
     "ihm2mpc_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "ihm2mpc_free": (C.c_int, [_H]),
     "ihm2mpc_synchronize": (C.c_int, [_H]),

@@ -12,11 +12,10 @@
 
 #include "ihm2mpc_internal.h"
 
-namespace {
+static thread_local std::string g_err;
 
-thread_local std::string g_err;
-
-int fail(const char *fmt, ...)
+// the error string of ihm2mpc_last_error, also set by comm.hip
+int ihm2_fail(const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -26,6 +25,10 @@ int fail(const char *fmt, ...)
     g_err = buf;
     return -1;
 }
+
+namespace {
+
+#define fail(...) ihm2_fail(__VA_ARGS__)
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -194,6 +197,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,

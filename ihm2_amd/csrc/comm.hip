@@ -1,0 +1,210 @@
+// comm.hip -- the ONE exchange step of the multi-GPU path: a final gather of the result blocks (u0, status) over
+// RCCL / xGMI, behind the C ABI and without PyTorch.  Instances are independent, so there is no data-path collective; every GPU
+// owns a contiguous block of the global batch (shard bounds are the caller's: ihm2_amd/dist.py::shard_bounds).
+//   * single process, one handle per device:  ihm2mpc_group_create (ncclCommInitAll) / _allgather_results / _free
+//   * one process per GPU (torch.distributed.run launches bench.py that way): ihm2mpc_comm_unique_id on rank 0, the 128 bytes travel
+//     by any side channel (ihm2_amd/dist.py: a TCP socket on MASTER_ADDR), ihm2mpc_comm_init on every rank, then
+//     ihm2mpc_comm_allgather_results / ihm2mpc_comm_allreduce_max (the bench's max-over-ranks timing) / ihm2mpc_comm_free.
+// Blocks may differ in size by construction of the block split: they are padded to the largest block for ncclAllGather (payload:
+// 20 bytes per instance) and trimmed on the host.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <string>
+#include <vector>
+
+#include "ihm2mpc_internal.h"
+
+extern int ihm2_fail(const char *fmt, ...);
+#define NCCL_TRY(call)                                                                                            \
+    do {                                                                                                          \
+        ncclResult_t r_ = (call);                                                                                 \
+        if (r_ != ncclSuccess) return ihm2_fail("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+#define HIPC_TRY(call)                                                                                            \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess) return ihm2_fail("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct ihm2mpc_group {
+    int n;
+    std::vector<ihm2mpc_handle *> h;
+    std::vector<ncclComm_t> comm;
+    std::vector<double *> send_u, recv_u;       // per device: (Bmax, 2), (n, Bmax, 2)
+    std::vector<int32_t *> send_s, recv_s;
+    int Bmax;
+};
+
+struct ihm2mpc_comm {
+    ncclComm_t comm;
+    int world, rank, Bmax;
+    double *send_u, *recv_u, *red;
+    int32_t *send_s, *recv_s;
+    std::vector<int> sizes;
+};
+
+static int alloc_bufs(int n, int Bmax, double **su, double **ru, int32_t **ss, int32_t **rs)
+{
+    HIPC_TRY(hipMalloc((void **)su, (size_t)Bmax * 2 * sizeof(double)));
+    HIPC_TRY(hipMalloc((void **)ru, (size_t)n * Bmax * 2 * sizeof(double)));
+    HIPC_TRY(hipMalloc((void **)ss, (size_t)Bmax * sizeof(int32_t)));
+    HIPC_TRY(hipMalloc((void **)rs, (size_t)n * Bmax * sizeof(int32_t)));
+    HIPC_TRY(hipMemset(*su, 0, (size_t)Bmax * 2 * sizeof(double)));
+    HIPC_TRY(hipMemset(*ss, 0, (size_t)Bmax * sizeof(int32_t)));
+    return 0;
+}
+
+extern "C" {
+
+int ihm2mpc_group_create(ihm2mpc_handle *const *handles, int32_t n, ihm2mpc_group **out)
+{
+    if (!handles || !out || n < 1) return ihm2_fail("null argument or n < 1");
+    std::vector<int> devs(n);
+    int Bmax = 0;
+    for (int i = 0; i < n; i++) {
+        if (!handles[i]) return ihm2_fail("null handle %d", i);
+        devs[i] = handles[i]->cfg.device;
+        for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return ihm2_fail("handles %d and %d live on the same device %d: one handle per device", j, i, devs[i]);
+        Bmax = std::max(Bmax, handles[i]->B);
+    }
+    ihm2mpc_group *g = new ihm2mpc_group();
+    g->n = n; g->Bmax = Bmax;
+    g->h.assign(handles, handles + n);
+    g->comm.resize(n); g->send_u.resize(n); g->recv_u.resize(n); g->send_s.resize(n); g->recv_s.resize(n);
+    NCCL_TRY(ncclCommInitAll(g->comm.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) {
+        HIPC_TRY(hipSetDevice(devs[i]));
+        if (alloc_bufs(n, Bmax, &g->send_u[i], &g->recv_u[i], &g->send_s[i], &g->recv_s[i])) return -1;
+    }
+    *out = g;
+    return 0;
+}
+
+// u0_all (sum of the B's, 2) and status_all (sum of the B's), host, in handle order; taken from device 0's receive buffers
+int ihm2mpc_group_allgather_results(ihm2mpc_group *g, double *u0_all, int32_t *status_all)
+{
+    if (!g || !u0_all || !status_all) return ihm2_fail("null argument");
+    for (int i = 0; i < g->n; i++) {
+        ihm2mpc_handle *h = g->h[i];
+        HIPC_TRY(hipSetDevice(h->cfg.device));
+        HIPC_TRY(hipMemcpyAsync(g->send_u[i], h->u0, (size_t)h->B * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HIPC_TRY(hipMemcpyAsync(g->send_s[i], h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < g->n; i++) {
+        NCCL_TRY(ncclAllGather(g->send_u[i], g->recv_u[i], (size_t)g->Bmax * 2, ncclDouble, g->comm[i], g->h[i]->stream));
+        NCCL_TRY(ncclAllGather(g->send_s[i], g->recv_s[i], (size_t)g->Bmax, ncclInt32, g->comm[i], g->h[i]->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < g->n; i++) {
+        HIPC_TRY(hipSetDevice(g->h[i]->cfg.device));
+        HIPC_TRY(hipStreamSynchronize(g->h[i]->stream));
+    }
+    HIPC_TRY(hipSetDevice(g->h[0]->cfg.device));
+    size_t off = 0;
+    for (int i = 0; i < g->n; i++) {
+        const size_t B = g->h[i]->B;
+        HIPC_TRY(hipMemcpy(u0_all + off * 2, g->recv_u[0] + (size_t)i * g->Bmax * 2, B * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPC_TRY(hipMemcpy(status_all + off, g->recv_s[0] + (size_t)i * g->Bmax, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+        off += B;
+    }
+    return 0;
+}
+
+int ihm2mpc_group_free(ihm2mpc_group *g)
+{
+    if (!g) return 0;
+    for (int i = 0; i < g->n; i++) {
+        (void)hipSetDevice(g->h[i]->cfg.device);
+        for (void *p : {(void *)g->send_u[i], (void *)g->recv_u[i], (void *)g->send_s[i], (void *)g->recv_s[i]}) if (p) (void)hipFree(p);
+        if (g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+    }
+    delete g;
+    return 0;
+}
+
+// ---- one process per GPU ----
+int ihm2mpc_comm_unique_id(uint8_t *id128)
+{
+    if (!id128) return ihm2_fail("null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+// sizes (world): instances of every rank's block (this rank's must equal the handle's batch)
+int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint8_t *id128, const int32_t *sizes)
+{
+    if (!h || !id128 || !sizes) return ihm2_fail("null argument");
+    if (world < 1 || rank < 0 || rank >= world) return ihm2_fail("rank %d out of range for world size %d", rank, world);
+    if (h->comm) return ihm2_fail("the handle already has a communicator");
+    if (sizes[rank] != h->B) return ihm2_fail("sizes[%d] = %d does not match the handle's batch %d", rank, sizes[rank], h->B);
+    HIPC_TRY(hipSetDevice(h->cfg.device));
+    ihm2mpc_comm *c = new ihm2mpc_comm();
+    c->world = world; c->rank = rank; c->Bmax = 0;
+    c->sizes.assign(sizes, sizes + world);
+    for (int r = 0; r < world; r++) c->Bmax = std::max(c->Bmax, (int)sizes[r]);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
+    if (alloc_bufs(world, c->Bmax, &c->send_u, &c->recv_u, &c->send_s, &c->recv_s)) return -1;
+    HIPC_TRY(hipMalloc((void **)&c->red, 2 * sizeof(double)));
+    h->comm = c;
+    return 0;
+}
+
+// u0_all (sum of sizes, 2), status_all (sum of sizes): host, in rank order, on every rank
+int ihm2mpc_comm_allgather_results(ihm2mpc_handle *h, double *u0_all, int32_t *status_all)
+{
+    if (!h || !h->comm || !u0_all || !status_all) return ihm2_fail("null argument or no communicator (ihm2mpc_comm_init)");
+    ihm2mpc_comm *c = h->comm;
+    HIPC_TRY(hipSetDevice(h->cfg.device));
+    HIPC_TRY(hipMemcpyAsync(c->send_u, h->u0, (size_t)h->B * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPC_TRY(hipMemcpyAsync(c->send_s, h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(ncclAllGather(c->send_u, c->recv_u, (size_t)c->Bmax * 2, ncclDouble, c->comm, h->stream));
+    NCCL_TRY(ncclAllGather(c->send_s, c->recv_s, (size_t)c->Bmax, ncclInt32, c->comm, h->stream));
+    NCCL_TRY(ncclGroupEnd());
+    HIPC_TRY(hipStreamSynchronize(h->stream));
+    size_t off = 0;
+    for (int r = 0; r < c->world; r++) {
+        const size_t B = c->sizes[r];
+        HIPC_TRY(hipMemcpy(u0_all + off * 2, c->recv_u + (size_t)r * c->Bmax * 2, B * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPC_TRY(hipMemcpy(status_all + off, c->recv_s + (size_t)r * c->Bmax, B * sizeof(int32_t), hipMemcpyDeviceToHost));
+        off += B;
+    }
+    return 0;
+}
+
+// *value <- max over the ranks of *value; doubles as the barrier of the timed region
+int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value)
+{
+    if (!h || !h->comm || !value) return ihm2_fail("null argument or no communicator (ihm2mpc_comm_init)");
+    ihm2mpc_comm *c = h->comm;
+    HIPC_TRY(hipSetDevice(h->cfg.device));
+    HIPC_TRY(hipMemcpyAsync(c->red, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(ncclAllReduce(c->red, c->red + 1, 1, ncclDouble, ncclMax, c->comm, h->stream));
+    HIPC_TRY(hipMemcpyAsync(value, c->red + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPC_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ihm2mpc_comm_free(ihm2mpc_handle *h)
+{
+    if (!h || !h->comm) return 0;
+    ihm2mpc_comm *c = h->comm;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    for (void *p : {(void *)c->send_u, (void *)c->recv_u, (void *)c->send_s, (void *)c->recv_s, (void *)c->red}) if (p) (void)hipFree(p);
+    (void)ncclCommDestroy(c->comm);
+    delete c;
+    h->comm = nullptr;
+    return 0;
+}
+
+}  // extern "C"

@@ -25,8 +25,11 @@
 #define QM_PAD 16    // >= 2 x ring depth of the vector / forward sweeps: their unclamped prefetch overshoots an instance by < 2 D rows
 #define LIN_REC 96   // doubles per (instance, interval) linearisation record: A (64) | B (16) | b (8) | rb (8: the QP's dynamics residual, riccati_mfma.hpp)
 
+struct ihm2mpc_comm;      // comm.hip: RCCL communicator + staging buffers of a one-process-per-GPU job
+
 struct ihm2mpc_handle {
     ihm2mpc_config cfg;
+    ihm2mpc_comm *comm;            // nullptr until ihm2mpc_comm_init
     int B, N, NS;
     int n_cu;                      // compute units of the device
     hipStream_t stream;

@@ -273,6 +273,24 @@ int ihm2mpc_get_cart_state(ihm2mpc_handle *h, double *x_cart, double *s_guess);
 int ihm2mpc_sim_advance_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps, double v_dyn,
                              double s_tol);
 
+/* ---- multi-GPU: the one exchange step of the path, RCCL over xGMI behind this ABI, no PyTorch ----
+ * Instances are independent: every GPU owns a contiguous block of the global batch and no collective runs on the data path; the
+ * results (u0, status: 20 bytes per instance) are gathered once at the end.  Blocks may differ in size (block split): they are
+ * padded to the largest block for the collective and trimmed on the host. */
+typedef struct ihm2mpc_group ihm2mpc_group;
+/* single process, one handle per device (ncclCommInitAll) */
+int ihm2mpc_group_create(ihm2mpc_handle *const *handles, int32_t n, ihm2mpc_group **out);
+/* u0_all (sum of the batches, 2), status_all (sum of the batches): host, in handle order */
+int ihm2mpc_group_allgather_results(ihm2mpc_group *g, double *u0_all, int32_t *status_all);
+int ihm2mpc_group_free(ihm2mpc_group *g);
+/* one process per GPU (as `python -m torch.distributed.run` launches bench.py): rank 0 makes the 128-byte id, a side channel
+ * carries it to the others (ihm2_amd/dist.py: a TCP socket on MASTER_ADDR), every rank joins; sizes (world) = instances per rank */
+int ihm2mpc_comm_unique_id(uint8_t *id128);
+int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint8_t *id128, const int32_t *sizes);
+int ihm2mpc_comm_allgather_results(ihm2mpc_handle *h, double *u0_all, int32_t *status_all);      /* host, rank order, on every rank */
+int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value);      /* in place; doubles as a barrier */
+int ihm2mpc_comm_free(ihm2mpc_handle *h);
+
 #ifdef __cplusplus
 }
 #endif
