@@ -139,6 +139,45 @@ __device__ __forceinline__ void dev_integrate_sens(
         }
 
     const double h = dt / M;
+    if (!S_IN_LDS) {
+        // fkin6: per sub-step FIRST the four stage evaluations of the state (the stage points depend on the state only), their
+        // Jacobians kept; THEN every sensitivity column through its four stages with the column's entries in registers throughout.
+        // Stage-major order (all columns per stage) moved S, Sacc and dK -- 156 values that do not fit the 256 vector registers
+        // next to the model evaluation -- between the accumulator file and the vector registers once per STAGE: 507 of the 1617
+        // instructions of a stage were v_accvgpr moves; column-major order touches S once per SUB-STEP.  Same arithmetic per
+        // column, bit-identical results.
+        for (int m = 0; m < M; m++) {
+            double xacc[8], K[8], J4[4][8][10];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+                const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+                double X[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+                fkin6_eval<true>(X, u_T, u_d, trk, K, J4[st]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = xacc[i];
+#define SUBSTEP_COL(c)                                                                                                   \
+            {                                                                                                            \
+                double Sa[8], dKc[8];                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) { Sa[i] = S[c][i]; dKc[i] = 0.0; }                          \
+                _Pragma("unroll") for (int st = 0; st < 4; st++) {                                                       \
+                    const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);                                       \
+                    const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);                          \
+                    sens_col_stage<MODEL, c>(J4[st], S[c], nullptr, Sa, dKc, ah, wh);                                    \
+                }                                                                                                        \
+                sens_col_copy<MODEL, c>(Sa, S[c]);                                                                       \
+            }
+            FOR_ALL_COLS(SUBSTEP_COL)
+#undef SUBSTEP_COL
+        }
+    } else
     for (int m = 0; m < M; m++) {
         double xacc[8], K[8];
 #pragma unroll
