@@ -12,7 +12,7 @@ using namespace ihm2;
 
 namespace {
 
-__device__ __forceinline__ double lat_pacejka_d(double alpha) { return lat_pacejka_t<double>(alpha); }
+__device__ __forceinline__ double lat_pacejka_d(double alpha) { return lat_pacejka_t(alpha); }
 
 // kin6: the fkin6 force model with Cartesian kinematics and r_dot = v_y_dot / l_R (python/models.py:226)
 __device__ inline void kin6_rhs(const double (&x)[8], double u_T, double u_delta, double (&f)[8])

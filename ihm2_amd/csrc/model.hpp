@@ -179,115 +179,273 @@ __device__ constexpr unsigned JU_MASK[2][8] = {{0u, 0u, 0u, 2u, 2u, 2u, 1u, 2u},
 __device__ constexpr unsigned S_COL_MASK[2][10] = {{0x07u, 0x07u, 0x07u, 0x3Fu, 0x3Fu, 0x27u, 0x7Fu, 0xBFu, 0x7Fu, 0xBFu},
                                                    {0x07u, 0x07u, 0x07u, 0x3Fu, 0x3Fu, 0x3Fu, 0x7Fu, 0xBFu, 0x7Fu, 0xBFu}};
 
-// ---- forward-mode dual numbers (value + ND directional derivatives) for the fdyn6 force model ----
-template <int ND>
-struct Dual {
-    double v;
-    double d[ND];
-};
-template <int ND> __device__ __forceinline__ Dual<ND> mk_const(double c) { Dual<ND> r; r.v = c; for (int i = 0; i < ND; i++) r.d[i] = 0.0; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> mk_var(double c, int idx) { Dual<ND> r = mk_const<ND>(c); r.d[idx] = 1.0; return r; }
-#define DUAL_UNARY(name, fv, dfv)                                                   \
-    template <int ND> __device__ __forceinline__ Dual<ND> name(const Dual<ND> &a)  \
-    {                                                                               \
-        Dual<ND> r; const double x = a.v; const double f = (fv); const double df = (dfv); (void)f; \
-        r.v = f;                                                                    \
-        _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = df * a.d[i];        \
-        return r;                                                                   \
-    }
-DUAL_UNARY(msin, sin(x), cos(x))
-DUAL_UNARY(mcos, cos(x), -sin(x))
-DUAL_UNARY(matan, atan(x), 1.0 / (1.0 + x * x))
-DUAL_UNARY(mtanh, tanh(x), 1.0 - f * f)
-DUAL_UNARY(mexp, exp(x), f)
-DUAL_UNARY(msqrt, sqrt(x), 0.5 / f)
-DUAL_UNARY(mtan, tan(x), 1.0 + f * f)
-#undef DUAL_UNARY
-__device__ __forceinline__ double msin(double x) { return sin(x); }
-__device__ __forceinline__ double mcos(double x) { return cos(x); }
-__device__ __forceinline__ double matan(double x) { return atan(x); }
-__device__ __forceinline__ double mtanh(double x) { return tanh(x); }
-__device__ __forceinline__ double mexp(double x) { return exp(x); }
-__device__ __forceinline__ double msqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ double mtan(double x) { return tan(x); }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; r.v = a.v + b.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; r.v = a.v - b.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND> &a) { Dual<ND> r; r.v = -a.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = -a.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; r.v = a.v * b.v; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = fma(a.v, b.d[i], a.d[i] * b.v); return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND> &a, const Dual<ND> &b) { Dual<ND> r; const double ib = 1.0 / b.v; r.v = a.v * ib; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND> &a, double c) { Dual<ND> r = a; r.v += c; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(double c, const Dual<ND> &a) { return a + c; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND> &a, double c) { Dual<ND> r = a; r.v -= c; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(double c, const Dual<ND> &a) { return (-a) + c; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND> &a, double c) { Dual<ND> r; r.v = a.v * c; _Pragma("unroll") for (int i = 0; i < ND; i++) r.d[i] = a.d[i] * c; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(double c, const Dual<ND> &a) { return a * c; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator/(const Dual<ND> &a, double c) { return a * (1.0 / c); }
-template <int ND> __device__ __forceinline__ Dual<ND> operator/(double c, const Dual<ND> &a) { return mk_const<ND>(c) / a; }
-__device__ __forceinline__ double val(double a) { return a; }
-template <int ND> __device__ __forceinline__ double val(const Dual<ND> &a) { return a.v; }
+// ---- transcendental functions of the dynamic model as CALLS ----
+// One body per function instead of one inlined copy per use (13 atan, 6 sincos, 5 tanh, 4 exp per evaluation of the force model):
+// the linearisation loop shrinks from 61 KB of code to 33 KB, i.e. under the 64 KB instruction cache two CUs share -- measured
+// 12.3 -> 6.3 ms for 8192 x 40 intervals, with MORE instructions executed (the inlined copies were specialised per site).
+static __device__ __noinline__ double nl_atan(double x) { return atan(x); }
+static __device__ __noinline__ double nl_exp(double x) { return exp(x); }
+static __device__ __noinline__ double2 nl_sincos(double x) { double sv, cv; sincos(x, &sv, &cv); return make_double2(sv, cv); }
+// tanh(y) = sign(y) (1 - t) / (1 + t), t = exp(-2 |y|): absolute error ~1e-16 (the relative error grows towards y = 0, where
+// every use multiplies the result by a quantity that vanishes with y)
+__device__ __forceinline__ double tanh_e(double y)
+{
+    const double t = exp(-2.0 * fabs(y));
+    return copysign((1.0 - t) / (1.0 + t), y);
+}
+static __device__ __noinline__ double nl_tanh(double y) { return tanh_e(y); }
 
-// ---- fdyn6: Frenet 4-wheel Pacejka model (python/models.py:455-606), explicit form ----
-// The tyre/chassis force model maps (v_x, v_y, r, T, delta) to (v_x_dot, v_y_dot, r_dot).  It is written once
-// over a scalar type T: double for the plant, Dual<5> for the OCP (15 Jacobian entries by forward AD).
-template <typename T>
-__device__ __forceinline__ T lat_pacejka_t(const T &alpha)
+// The two per-wheel functions are calls as well (four uses each per evaluation), with their own transcendentals inlined: a call
+// inside a call costs a link-register spill (7.1 ms with nested calls against 6.3 ms).
+// slip angle alpha = atan(v_lat / smooth_abs_nonzero(v_lon)), smooth_abs_nonzero(v) = tanh(10 v) v + 1e-6 exp(-v^2)
+// (python/models.py:417-421,533-541), and its two partial derivatives
+struct SlipD { double a, d_lat, d_lon; };
+static __device__ __noinline__ SlipD nl_slip_d(double v_lat, double v_lon)
+{
+    const double th = tanh_e(10.0 * v_lon), e = exp(-(v_lon * v_lon));
+    const double xs = fma(th, v_lon, 1e-6 * e);
+    const double dxs = th + 10.0 * v_lon * fma(-th, th, 1.0) - 2e-6 * v_lon * e;
+    const double ix = 1.0 / xs, q = v_lat * ix;
+    const double w = ix / fma(q, q, 1.0);            // d atan(q) / dq  x  dq / dv_lat
+    SlipD r; r.a = atan(q); r.d_lat = w; r.d_lon = -w * q * dxs;
+    return r;
+}
+static __device__ __noinline__ double nl_slip(double v_lat, double v_lon)
+{
+    const double th = tanh_e(10.0 * v_lon), e = exp(-(v_lon * v_lon));
+    return atan(v_lat / fma(th, v_lon, 1e-6 * e));
+}
+// lateral Pacejka force coefficient (python/models.py:423-440) and its derivative
+struct PacD { double g, dg; };
+static __device__ __noinline__ PacD nl_pacejka_d(double alpha)
 {
     const double BCDa = k_b1a * sin(2.0 * atan(k_static_weight / k_b2a));
     const double Ca = k_c1a, Da = k_d1a * k_static_weight + k_d2a, Ea = k_e1a * k_static_weight + k_e2a;
     const double Ba = BCDa / (Ca * Da);
-    const T Bx = alpha * Ba;
-    return msin(matan(Bx - (Bx - matan(Bx)) * Ea) * Ca) * Da;
+    const double Bx = alpha * Ba;
+    const double t1 = atan(Bx), dt1 = 1.0 / fma(Bx, Bx, 1.0);
+    const double in = Bx - (Bx - t1) * Ea, din = 1.0 - (1.0 - dt1) * Ea;
+    const double t2 = atan(in), dt2 = din / fma(in, in, 1.0);
+    double sv, cv;
+    sincos(t2 * Ca, &sv, &cv);
+    PacD r; r.g = sv * Da; r.dg = cv * (Da * Ca * Ba) * dt2;
+    return r;
 }
-template <typename T>
-__device__ __forceinline__ T smooth_abs_nonzero_t(const T &v) { return mtanh(v * 10.0) * v + mexp(-(v * v)) * 1e-6; }
-
-template <typename T, bool UNCROSSED>
-__device__ inline void fdyn6_forces(const T &v_x, const T &v_y, const T &r, const T &Tq, const T &delta, T &vxd, T &vyd, T &rd)
+static __device__ __noinline__ double nl_pacejka(double alpha)
 {
-    const T sd = msin(delta), cd = mcos(delta);
-    const T F_down = v_x * v_x * (0.5 * k_Cdown);
+    const double BCDa = k_b1a * sin(2.0 * atan(k_static_weight / k_b2a));
+    const double Ca = k_c1a, Da = k_d1a * k_static_weight + k_d2a, Ea = k_e1a * k_static_weight + k_e2a;
+    const double Ba = BCDa / (Ca * Da);
+    const double Bx = alpha * Ba;
+    return sin(atan(Bx - (Bx - atan(Bx)) * Ea) * Ca) * Da;
+}
+
+// scalar instantiation of the generic force model (the plants)
+__device__ __forceinline__ double msin(double x) { return nl_sincos(x).x; }
+__device__ __forceinline__ double matan(double x) { return nl_atan(x); }
+__device__ __forceinline__ double mtanh(double x) { return nl_tanh(x); }
+__device__ __forceinline__ double msqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double val(double a) { return a; }
+
+// ---- sparse forward-mode duals: value + the directional derivatives named by the bits of MASK (bit k = d / d input k) ----
+// The force model's intermediates depend on one to five of its inputs (sin(delta): one; a rear slip angle: three; the load
+// transfer: all five).  Dual<5> carries five derivative slots through all of them, and without fast-math the compiler may not
+// drop the products with the literal zeros of the seeds; SD<MASK> does not have the slots in the first place: the result type of an
+// operation is the union of its operands' masks, resolved at compile time.
+__host__ __device__ constexpr int sd_pc(unsigned m) { int n = 0; for (; m; m >>= 1) n += (int)(m & 1u); return n; }
+__host__ __device__ constexpr int sd_ix(unsigned m, int k) { return sd_pc(m & ((1u << k) - 1u)); }
+template <unsigned MASK>
+struct SD {
+    double v;
+    double d[sd_pc(MASK) ? sd_pc(MASK) : 1];
+};
+#define SD_HAS(M, k) ((((M) >> (k)) & 1u) != 0u)
+#define SD_BITS(OP) OP(0) OP(1) OP(2) OP(3) OP(4)
+template <unsigned M> __device__ __forceinline__ SD<M> sd_seed(double v)      // the input itself: MASK has exactly one bit
+{
+    SD<M> r; r.v = v; r.d[0] = 1.0; return r;
+}
+template <unsigned TO, unsigned M> __device__ __forceinline__ SD<TO> sd_widen(const SD<M> &a)
+{
+    static_assert((M & ~TO) == 0u, "widening only");
+    SD<TO> r; r.v = a.v;
+#define OP(k) if constexpr (SD_HAS(TO, k)) { if constexpr (SD_HAS(M, k)) r.d[sd_ix(TO, k)] = a.d[sd_ix(M, k)]; else r.d[sd_ix(TO, k)] = 0.0; }
+    SD_BITS(OP)
+#undef OP
+    return r;
+}
+template <unsigned A, unsigned B> __device__ __forceinline__ SD<A | B> operator+(const SD<A> &a, const SD<B> &b)
+{
+    SD<A | B> r; r.v = a.v + b.v;
+#define OP(k) if constexpr (SD_HAS(A | B, k)) {                                                                        \
+        if constexpr (SD_HAS(A, k) && SD_HAS(B, k)) r.d[sd_ix(A | B, k)] = a.d[sd_ix(A, k)] + b.d[sd_ix(B, k)];         \
+        else if constexpr (SD_HAS(A, k)) r.d[sd_ix(A | B, k)] = a.d[sd_ix(A, k)];                                       \
+        else r.d[sd_ix(A | B, k)] = b.d[sd_ix(B, k)]; }
+    SD_BITS(OP)
+#undef OP
+    return r;
+}
+template <unsigned A, unsigned B> __device__ __forceinline__ SD<A | B> operator-(const SD<A> &a, const SD<B> &b)
+{
+    SD<A | B> r; r.v = a.v - b.v;
+#define OP(k) if constexpr (SD_HAS(A | B, k)) {                                                                        \
+        if constexpr (SD_HAS(A, k) && SD_HAS(B, k)) r.d[sd_ix(A | B, k)] = a.d[sd_ix(A, k)] - b.d[sd_ix(B, k)];         \
+        else if constexpr (SD_HAS(A, k)) r.d[sd_ix(A | B, k)] = a.d[sd_ix(A, k)];                                       \
+        else r.d[sd_ix(A | B, k)] = -b.d[sd_ix(B, k)]; }
+    SD_BITS(OP)
+#undef OP
+    return r;
+}
+template <unsigned A, unsigned B> __device__ __forceinline__ SD<A | B> operator*(const SD<A> &a, const SD<B> &b)
+{
+    SD<A | B> r; r.v = a.v * b.v;
+#define OP(k) if constexpr (SD_HAS(A | B, k)) {                                                                                          \
+        if constexpr (SD_HAS(A, k) && SD_HAS(B, k)) r.d[sd_ix(A | B, k)] = fma(a.v, b.d[sd_ix(B, k)], a.d[sd_ix(A, k)] * b.v);            \
+        else if constexpr (SD_HAS(A, k)) r.d[sd_ix(A | B, k)] = a.d[sd_ix(A, k)] * b.v;                                                   \
+        else r.d[sd_ix(A | B, k)] = a.v * b.d[sd_ix(B, k)]; }
+    SD_BITS(OP)
+#undef OP
+    return r;
+}
+template <unsigned A, unsigned B> __device__ __forceinline__ SD<A | B> operator/(const SD<A> &a, const SD<B> &b)
+{
+    SD<A | B> r; const double ib = 1.0 / b.v; r.v = a.v * ib;
+#define OP(k) if constexpr (SD_HAS(A | B, k)) {                                                                                          \
+        if constexpr (SD_HAS(A, k) && SD_HAS(B, k)) r.d[sd_ix(A | B, k)] = (a.d[sd_ix(A, k)] - r.v * b.d[sd_ix(B, k)]) * ib;              \
+        else if constexpr (SD_HAS(A, k)) r.d[sd_ix(A | B, k)] = a.d[sd_ix(A, k)] * ib;                                                    \
+        else r.d[sd_ix(A | B, k)] = -(r.v * b.d[sd_ix(B, k)]) * ib; }
+    SD_BITS(OP)
+#undef OP
+    return r;
+}
+template <unsigned M> __device__ __forceinline__ SD<M> operator-(const SD<M> &a) { SD<M> r; r.v = -a.v; _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = -a.d[i]; return r; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator+(const SD<M> &a, double c) { SD<M> r = a; r.v += c; return r; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator+(double c, const SD<M> &a) { return a + c; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator-(const SD<M> &a, double c) { SD<M> r = a; r.v -= c; return r; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator-(double c, const SD<M> &a) { return (-a) + c; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator*(const SD<M> &a, double c) { SD<M> r; r.v = a.v * c; _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = a.d[i] * c; return r; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator*(double c, const SD<M> &a) { return a * c; }
+template <unsigned M> __device__ __forceinline__ SD<M> operator/(const SD<M> &a, double c) { return a * (1.0 / c); }
+template <unsigned M> __device__ __forceinline__ SD<M> operator/(double c, const SD<M> &a)
+{
+    SD<M> r; const double ia = 1.0 / a.v; r.v = c * ia; const double f = -r.v * ia;
+    _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = f * a.d[i];
+    return r;
+}
+#define SD_UNARY(name, fv, dfv)                                                                   \
+    template <unsigned M> __device__ __forceinline__ SD<M> name(const SD<M> &a)                  \
+    {                                                                                             \
+        SD<M> r; const double x = a.v; const double f = (fv); const double df = (dfv); (void)f;    \
+        r.v = f;                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = df * a.d[i];                \
+        return r;                                                                                 \
+    }
+SD_UNARY(matan, nl_atan(x), 1.0 / fma(x, x, 1.0))
+SD_UNARY(mtanh, nl_tanh(x), fma(-f, f, 1.0))
+SD_UNARY(msqrt, sqrt(x), 0.5 / f)
+#undef SD_UNARY
+// sine with its derivative factor from the same range reduction
+template <unsigned M> __device__ __forceinline__ SD<M> msin(const SD<M> &a)
+{
+    SD<M> r; const double2 sc = nl_sincos(a.v); r.v = sc.x;
+    _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = sc.y * a.d[i];
+    return r;
+}
+template <unsigned M> __device__ __forceinline__ void msincos(const SD<M> &a, SD<M> &s, SD<M> &c)
+{
+    const double2 sc = nl_sincos(a.v); s.v = sc.x; c.v = sc.y;
+    _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) { s.d[i] = sc.y * a.d[i]; c.d[i] = -sc.x * a.d[i]; }
+}
+__device__ __forceinline__ void msincos(double a, double &s, double &c) { const double2 sc = nl_sincos(a); s = sc.x; c = sc.y; }
+// f(a, b) from its value and its two partial derivatives
+template <unsigned A, unsigned B> __device__ __forceinline__ SD<A | B> sd_chain2(double f, double fa, double fb, const SD<A> &a, const SD<B> &b)
+{
+    SD<A | B> r; r.v = f;
+#define OP(k) if constexpr (SD_HAS(A | B, k)) {                                                                                  \
+        if constexpr (SD_HAS(A, k) && SD_HAS(B, k)) r.d[sd_ix(A | B, k)] = fma(fa, a.d[sd_ix(A, k)], fb * b.d[sd_ix(B, k)]);      \
+        else if constexpr (SD_HAS(A, k)) r.d[sd_ix(A | B, k)] = fa * a.d[sd_ix(A, k)];                                            \
+        else r.d[sd_ix(A | B, k)] = fb * b.d[sd_ix(B, k)]; }
+    SD_BITS(OP)
+#undef OP
+    return r;
+}
+template <unsigned A, unsigned B> __device__ __forceinline__ SD<A | B> slip_angle_t(const SD<A> &v_lat, const SD<B> &v_lon)
+{
+    const SlipD sl = nl_slip_d(v_lat.v, v_lon.v);
+    return sd_chain2(sl.a, sl.d_lat, sl.d_lon, v_lat, v_lon);
+}
+__device__ __forceinline__ double slip_angle_t(double v_lat, double v_lon) { return nl_slip(v_lat, v_lon); }
+template <unsigned M> __device__ __forceinline__ SD<M> lat_pacejka_t(const SD<M> &alpha)
+{
+    const PacD pc = nl_pacejka_d(alpha.v);
+    SD<M> r; r.v = pc.g;
+    _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = pc.dg * alpha.d[i];
+    return r;
+}
+__device__ __forceinline__ double lat_pacejka_t(double alpha) { return nl_pacejka(alpha); }
+template <unsigned M> __device__ __forceinline__ double val(const SD<M> &a) { return a.v; }
+// compile-time choice between two expressions of different types
+template <bool FIRST, typename TA, typename TB> __device__ __forceinline__ auto sd_sel(const TA &a, const TB &b)
+{
+    if constexpr (FIRST) return a; else return b;
+}
+__device__ __forceinline__ void sd_assign(double &dst, double src) { dst = src; }
+template <unsigned TO, unsigned M> __device__ __forceinline__ void sd_assign(SD<TO> &dst, const SD<M> &src) { dst = sd_widen<TO>(src); }
+
+// ---- fdyn6: Frenet 4-wheel Pacejka model (python/models.py:455-606), explicit form ----
+// The tyre/chassis force model maps (v_x, v_y, r, T, delta) to (v_x_dot, v_y_dot, r_dot).  It is written once over scalar types:
+// double for the plant, sparse duals seeded on the five inputs for the OCP (15 Jacobian entries by forward AD).
+template <bool UNCROSSED, typename TVX, typename TVY, typename TR, typename TT, typename TD, typename TO>
+__device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r, const TT &Tq, const TD &delta, TO &vxd, TO &vyd, TO &rd)
+{
+    TD sd, cd;
+    msincos(delta, sd, cd);
+    const auto F_down = v_x * v_x * (0.5 * k_Cdown);
     const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track;
-    const T base = F_down * 0.25 + k_static_weight;
+    const auto base = F_down * 0.25 + k_static_weight;
     const double hx = 0.5 * k_axle_track;
-    const T v_x_FL = v_x - r * hx, v_x_FR = v_x + r * hx, v_y_F = v_y + r * k_lF;
-    const T v_lon_FL = cd * v_x_FL + sd * v_y_F, v_lon_FR = cd * v_x_FR + sd * v_y_F;
-    const T v_lat_FL = cd * v_y_F - sd * v_x_FL, v_lat_FR = cd * v_y_F - sd * v_x_FR;
-    const T v_lat_R = v_y - r * k_lR;
+    const auto v_x_FL = v_x - r * hx, v_x_FR = v_x + r * hx;
+    const auto v_y_F = v_y + r * k_lF;
+    const auto v_lon_FL = cd * v_x_FL + sd * v_y_F, v_lon_FR = cd * v_x_FR + sd * v_y_F;
+    const auto v_lat_FL = cd * v_y_F - sd * v_x_FL, v_lat_FR = cd * v_y_F - sd * v_x_FR;
+    const auto v_lat_R = v_y - r * k_lR;
     // slip angles: atan2(y, x) with x = smooth_abs_nonzero(.) > 0  ->  atan(y / x)
-    const T a_FL = matan(v_lat_FL / smooth_abs_nonzero_t(v_lon_FL));
-    const T a_FR = matan(v_lat_FR / smooth_abs_nonzero_t(v_lon_FR));
-    const T a_RL = matan(v_lat_R / smooth_abs_nonzero_t(v_x_FL));      // v_lon_RL = v_x - hx r
-    const T a_RR = matan(v_lat_R / smooth_abs_nonzero_t(v_x_FR));      // v_lon_RR = v_x + hx r
+    const auto a_FL = slip_angle_t(v_lat_FL, v_lon_FL);
+    const auto a_FR = slip_angle_t(v_lat_FR, v_lon_FR);
+    const auto a_RL = slip_angle_t(v_lat_R, v_x_FL);      // v_lon_RL = v_x - hx r
+    const auto a_RR = slip_angle_t(v_lat_R, v_x_FR);      // v_lon_RR = v_x + hx r
     // crossed slip angles exactly as models.py:543-546 (quirk Q3); order FL, FR, RL, RR.  UNCROSSED (model "fdyn6u") gives every
     // wheel its own slip angle: the crossed form is open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s)
-    const T glat0 = lat_pacejka_t(UNCROSSED ? a_FL : a_RR), glat1 = lat_pacejka_t(UNCROSSED ? a_FR : a_RL);
-    const T glat2 = lat_pacejka_t(UNCROSSED ? a_RL : a_FR), glat3 = lat_pacejka_t(UNCROSSED ? a_RR : a_FL);
-    const T F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
-    const T beta = matan(mtan(delta) * k_rwd);
-    const T r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
-    const T dtau = (r_kin - r) * k_Ktv;
-    const T denom = F_down * (-0.25) - k_m * k_g;
-    const T gm = (Tq - dtau) * k_Cm0 / denom, gp = (Tq + dtau) * k_Cm0 / denom;      // glon: FL, RL = gm ; FR, RR = gp
-    const T cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;   // FL
-    const T cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;   // FR
-    const T cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
-    const T cz2 = -(gm * hx) - glat2 * k_lR, cz3 = gp * hx - glat3 * k_lR;
+    const auto glat0 = lat_pacejka_t(sd_sel<UNCROSSED>(a_FL, a_RR));
+    const auto glat1 = lat_pacejka_t(sd_sel<UNCROSSED>(a_FR, a_RL));
+    const auto glat2 = lat_pacejka_t(sd_sel<UNCROSSED>(a_RL, a_FR));
+    const auto glat3 = lat_pacejka_t(sd_sel<UNCROSSED>(a_RR, a_FL));
+    const auto F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
+    const auto beta = matan((sd / cd) * k_rwd);                            // tan(delta) = sin / cos
+    const auto r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
+    const auto dtau = (r_kin - r) * k_Ktv;
+    const auto idenom = k_Cm0 / (F_down * (-0.25) - k_m * k_g);
+    const auto gm = (Tq - dtau) * idenom, gp = (Tq + dtau) * idenom;      // glon: FL, RL = gm ; FR, RR = gp
+    const auto cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;   // FL
+    const auto cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;   // FR
+    const auto cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
+    const auto cz2 = -(gm * hx) - glat2 * k_lR, cz3 = gp * hx - glat3 * k_lR;
     // m a_x = X0 + Xx a_x + Xy a_y ; m a_y = Y0 + Yx a_x + Yy a_y with F_z,k = -(base + sx_k cx a_x + sy_k cy a_y),
     // sx = (-,-,+,+), sy = (+,-,+,-)
-    const T sumx = cx0 + cx1 + gm + gp, sumy = cy0 + cy1 + glat2 + glat3;
-    const T X0 = F_drag - sumx * base, Y0 = -(sumy * base);
-    const T Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
-    const T Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
-    const T a11 = -Xx + k_m, a12 = -Xy, a21 = -Yx, a22 = -Yy + k_m;
-    const T det = a11 * a22 - a12 * a21;
-    const T a_x = (X0 * a22 - a12 * Y0) / det;
-    const T a_y = (a11 * Y0 - a21 * X0) / det;
-    const T lx = a_x * cx, ly = a_y * cy;
-    const T Fz0 = -(base - lx + ly), Fz1 = -(base - lx - ly), Fz2 = -(base + lx + ly), Fz3 = -(base + lx - ly);
-    const T Mz = cz0 * Fz0 + cz1 * Fz1 + cz2 * Fz2 + cz3 * Fz3;
-    vxd = a_x + v_y * r;
-    vyd = a_y - v_x * r;
-    rd = Mz * (1.0 / k_Iz);
+    const auto sumx = cx0 + cx1 + gm + gp, sumy = cy0 + cy1 + glat2 + glat3;
+    const auto X0 = F_drag - sumx * base, Y0 = -(sumy * base);
+    const auto Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
+    const auto Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
+    const auto a11 = -Xx + k_m, a12 = -Xy, a21 = -Yx, a22 = -Yy + k_m;
+    const auto det = a11 * a22 - a12 * a21;
+    const auto a_x = (X0 * a22 - a12 * Y0) / det;
+    const auto a_y = (a11 * Y0 - a21 * X0) / det;
+    const auto lx = a_x * cx, ly = a_y * cy;
+    const auto Fz0 = -(base - lx + ly), Fz1 = -(base - lx - ly), Fz2 = -(base + lx + ly), Fz3 = -(base + lx - ly);
+    const auto Mz = cz0 * Fz0 + cz1 * Fz1 + cz2 * Fz2 + cz3 * Fz3;
+    sd_assign(vxd, a_x + v_y * r);
+    sd_assign(vyd, a_y - v_x * r);
+    sd_assign(rd, Mz * (1.0 / k_Iz));
 }
 
 // xdot (and with WITH_JAC the structural non-zeros of its Jacobian, pattern JX_MASK[1] / JU_MASK[1])
@@ -308,9 +466,8 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
     f[6] = (u_T - T) * (1.0 / k_tT);
     f[7] = (u_delta - delta) * (1.0 / k_tdelta);
     if (WITH_JAC) {
-        typedef Dual<5> D5;
-        D5 o0, o1, o2;
-        fdyn6_forces<D5, UNCROSSED>(mk_var<5>(v_x, 0), mk_var<5>(v_y, 1), mk_var<5>(r, 2), mk_var<5>(T, 3), mk_var<5>(delta, 4), o0, o1, o2);
+        SD<0x1Fu> o0, o1, o2;
+        fdyn6_forces<UNCROSSED>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
         f[3] = o0.v; f[4] = o1.v; f[5] = o2.v;
 #pragma unroll
         for (int c = 0; c < 5; c++) { J[3][3 + c] = o0.d[c]; J[4][3 + c] = o1.d[c]; J[5][3 + c] = o2.d[c]; }
@@ -334,7 +491,7 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
         J[7][7] = -1.0 / k_tdelta;
         J[7][9] = 1.0 / k_tdelta;
     } else {
-        fdyn6_forces<double, UNCROSSED>(v_x, v_y, r, T, delta, f[3], f[4], f[5]);
+        fdyn6_forces<UNCROSSED>(v_x, v_y, r, T, delta, f[3], f[4], f[5]);
     }
 }
 
