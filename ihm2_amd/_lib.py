@@ -76,6 +76,7 @@ SYMBOLS = {
     "ihm2mpc_get_status": (C.c_int, [_H, c_int32_p]),
     "ihm2mpc_get_qp_iter": (C.c_int, [_H, c_int32_p]),
     "ihm2mpc_get_residuals": (C.c_int, [_H, c_double_p]),
+    "ihm2mpc_get_qp_residuals": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_multipliers": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_get_slacks": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_slacks": (C.c_int, [_H, c_double_p]),

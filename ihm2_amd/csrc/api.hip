@@ -184,7 +184,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     for (size_t i = 0; i < NS * NC; i++) { h->host_lb[i] = -INFINITY; h->host_ub[i] = INFINITY; }
     for (size_t i = 0; i < NS * NLAM; i++) { h->host_sz[i] = 0.0; h->host_sZ[i] = -1.0; }
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
-    DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(status, B); DA(qp_iter, B); DA(active, B); DA(u0, B * 2);
+    DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(qp_res, B * 4); DA(status, B); DA(qp_iter, B); DA(active, B); DA(u0, B * 2);
     DA(lin, (B * N + B) * LIN_REC);      // + one spare record per instance (the kinematic plant's, never read)
     DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, (B * N + 2 * QM_PAD) * 64); DA(scratch, B * 24);
 #undef DA
@@ -199,7 +199,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
@@ -677,6 +677,7 @@ GETTER(x, x, h->NS * NX)
 GETTER(u, u, h->N * NU)
 GETTER(u0, u0, NU)
 GETTER(residuals, res, 4)
+GETTER(qp_residuals, qp_res, 4)
 GETTER(x0, x0, NX)
 GETTER(slacks, slk, h->NS * NLAM)
 #undef GETTER

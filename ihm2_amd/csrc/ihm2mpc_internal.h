@@ -78,6 +78,7 @@ struct ihm2mpc_handle {
     double *lam;    // (B,NS,28)
     double *slk;    // (B,NS,28) slack values of the soft sides after the last QP (0 for hard sides)
     double *res;    // (B,4)
+    double *qp_res; // (B,4) KKT residuals of the QP at its returned point, relative to the scales of its tolerances
     int32_t *status, *qp_iter;   // (B)
     int32_t *active;             // (B) plant mask of the device-resident closed loop (nullptr-equivalent while !active_set)
     bool active_set;

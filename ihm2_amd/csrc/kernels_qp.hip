@@ -49,7 +49,7 @@ struct QpArgs {
     // per instance
     double *x, *u;
     const double *x0, *yref, *yref_e;
-    double *pi, *lam, *res, *u0;
+    double *pi, *lam, *res, *qp_res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
     double *g, *P, *M, *slk;
@@ -191,6 +191,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *hc = tile + 136;         // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
     double *Hl = hc + (PATH ? NS * 2 : 0);   // 200  stage and terminal Hessian (HL only)
     double *CDl = Hl + (HL ? 200 : 0);       // 20   general rows (CL only)
+    double *spv = CDl + (CL ? 20 : 0);       // 60   the (up to three) non-zeros of every row of the two Hessians (HL only) ...
+    int *spc = reinterpret_cast<int *>(spv + 60);      // 60 ints: ... and their columns
 #define HS(k, i, l) (HL ? Hl[(((k) == N) ? 100 : 0) + (i) * 10 + (l)] : a.Hs[((k) * 10 + (i)) * 10 + (l)])
 #define CDV(k, r, j) (CL ? CDl[(r) * 10 + (j)] : a.CD[((k) * 2 + (r)) * 10 + (j)])
 
@@ -209,6 +211,23 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     if (HL) for (int e = lane; e < 200; e += 64) Hl[e] = a.Hs[(e < 100) ? e : N * 100 + (e - 100)];
     if (CL && lane < 20) CDl[lane] = a.CD[lane];
     if (UNI) WSYNC();
+    // Rows of the batch-shared Hessians with at most three non-zeros each (the reference's cost y = [x; u; x_act - u], python/mpc.py:49-58,
+    // couples an actuator state with its own input only): phase (i) of every iteration then multiplies the non-zeros alone, in column
+    // order -- the same sums as the dense loop, whose other terms are exact zeros.
+    bool h_sparse = false;
+    if (HL) {
+        int cnt = 0;
+        if (lane < 20) {
+#pragma unroll
+            for (int l = 0; l < 10; l++) {
+                const double v = Hl[lane * 10 + l];
+                if (v != 0.0) { if (cnt < 3) { spv[lane * 3 + cnt] = v; spc[lane * 3 + cnt] = l; } cnt++; }
+            }
+            for (int q = cnt; q < 3; q++) { spv[lane * 3 + q] = 0.0; spc[lane * 3 + q] = 0; }
+        }
+        h_sparse = __ballot(cnt > 3) == 0ull;
+        WSYNC();
+    }
     double sg = 1.0, sb = 1.0, r_stat = 0.0, r_eq = 0.0;
     double w_R = 0.0, w_L = 0.0;
     if (PATH) {
@@ -405,8 +424,14 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         for (int e = lane; e < NS * 10; e += 64) {
             const int k = e / 10, j = e % 10;
             double acc = gb[e];
+            if (HL && h_sparse) {
+                const int row = ((k == N) ? 10 : 0) + j;
 #pragma unroll
-            for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
+                for (int q = 0; q < 3; q++) acc = fma(spv[row * 3 + q], z[k * 10 + spc[row * 3 + q]], acc);
+            } else {
+#pragma unroll
+                for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
+            }
             if (k < N) {
                 acc = fma(-CDV(k, 0, j), cf[k * NCK + 10], acc);
                 acc = fma(-CDV(k, 1, j), cf[k * NCK + 11], acc);
@@ -773,7 +798,13 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     }
     __syncthreads();
     if (lane < 2) a.u0[(size_t)b * 2 + lane] = uw[lane];
-    if (lane == 0) { a.status[b] = st; a.qp_iter[b] = it; }
+    if (lane == 0) {
+        a.status[b] = st; a.qp_iter[b] = it;
+        // the QP's own KKT residuals where the iteration stopped, relative to the scales its tolerance is taken against
+        // (stationarity, dynamics, inequalities, complementarity: <= ipm_tol each for status 0)
+        double *q = a.qp_res + (size_t)b * 4;
+        q[0] = res_g / sg; q[1] = res_b / sb; q[2] = res_d / sb; q[3] = res_m / sg;
+    }
 }
 
 template <int NSLOT, int NSOFT, int PATH, int UNI>
@@ -936,7 +967,7 @@ static size_t qp_lds_bytes(const ihm2mpc_handle *h)
     const size_t N = h->N, NS = h->NS;
     const int nck = h->path_on ? 14 : 12;
     const int uni = h->uniform_H && h->uniform_CD;
-    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 4 + 16 + 8 + 8) + 136 + (uni ? 20 + (h->path_on ? 0 : 200) : 0));
+    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 4 + 16 + 8 + 8) + 136 + (uni ? 20 + (h->path_on ? 0 : 200 + 90) : 0));
 }
 
 static QpArgs qp_args(ihm2mpc_handle *h)
@@ -946,7 +977,7 @@ static QpArgs qp_args(ihm2mpc_handle *h)
     a.tol = h->cfg.ipm_tol; a.mu0 = h->cfg.ipm_mu0; a.tau0 = h->cfg.ipm_tau0;
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
-    a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
+    a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.qp_res = h->qp_res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
     a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
     a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;

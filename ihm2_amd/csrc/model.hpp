@@ -78,6 +78,46 @@ struct TrackSeg {
     }
 };
 
+// ---- lean sine / cosine / tanh for the model evaluations ----
+// The models call sincos on the heading error and the steering angle (|x| << 1) and tanh on 10 v_x, four times per RK4 sub-step and
+// interval.  The library versions carry the Payne-Hanek path for huge arguments and ~190 instructions per sincos, ~180 per tanh; these
+// take ~50 and ~75: three-constant Cody-Waite reduction (exact for the n = 0 case the models live in, error < 1e-16 |x| up to 1e5),
+// fdlibm's kernel polynomials (< 1 ulp on [-pi/4, pi/4]); beyond 1e5 the library function is called.
+static __device__ __noinline__ double2 sincos_lib(double x) { double sv, cv; sincos(x, &sv, &cv); return make_double2(sv, cv); }
+__device__ __forceinline__ void fast_sincos(double x, double *sp, double *cp)
+{
+    const double n = rint(x * 6.36619772367581382433e-01);                 // 2 / pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    r = fma(-n, -1.49738490485916983693e-33, r);           // pi/2 = P1 + P2 + P3, to 2^-161
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sv = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cv = 1.0 - fma(0.5, z, -(z * z) * pc);
+    const int q = (int)n;
+    double so = (q & 1) ? cv : sv, co = (q & 1) ? sv : cv;
+    so = (q & 2) ? -so : so;
+    co = ((q + 1) & 2) ? -co : co;
+    if (!(fabs(x) <= 1e5)) { const double2 l = sincos_lib(x); so = l.x; co = l.y; }      // huge, inf, nan
+    *sp = so; *cp = co;
+}
+// tanh(y) = sign(y) (1 - t) / (1 + t), t = exp(-2 |y|): absolute error ~1e-16 (the relative error grows towards y = 0, where
+// every use multiplies the result by a quantity that vanishes with y)
+__device__ __forceinline__ double tanh_e(double y)
+{
+    const double t = exp(-2.0 * fabs(y));
+    return copysign((1.0 - t) / (1.0 + t), y);
+}
+
 // ---- fkin6: xdot and the 31 structural non-zeros of d xdot / d (x,u) ----
 // J[i][j], j < 8: d/dx_j ; j = 8: d/du_T ; j = 9: d/du_delta.  Entries that are structurally zero
 // are never written and never read.
@@ -91,7 +131,7 @@ __device__ __forceinline__ void fkin6_eval(const double (&x)[8], double u_T, dou
     const double T_dot = (u_T - T) * (1.0 / k_tT);
     // longitudinal forces (models.py:255-258)
     const double F_motor = k_Cm0 * T;
-    const double sg = tanh(10.0 * v_x);
+    const double sg = tanh_e(10.0 * v_x);
     const double poly = k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x;
     const double F_drag = -poly * sg;
     const double F_Rx = 0.5 * F_motor + F_drag, F_Fx = 0.5 * F_motor;
@@ -99,7 +139,7 @@ __device__ __forceinline__ void fkin6_eval(const double (&x)[8], double u_T, dou
     // one rsqrt replace tan, atan, sincos(beta) and sincos(delta - beta):
     //   cos(beta) = cd / sqrt(cd^2 + c^2 sd^2), sin(beta) = c sd / sqrt(cd^2 + c^2 sd^2)   (cd > 0 for |delta| < pi/2)
     double sd, cd;
-    sincos(delta, &sd, &cd);
+    fast_sincos(delta, &sd, &cd);
     const double td = sd / cd;
     const double hyp = 1.0 / sqrt(cd * cd + c * c * sd * sd);
     const double cb = cd * hyp, sb = c * sd * hyp;
@@ -112,7 +152,7 @@ __device__ __forceinline__ void fkin6_eval(const double (&x)[8], double u_T, dou
     double dk;
     const double kap = trk.kappa(x[0], dk);
     double sp, cp;
-    sincos(psi, &sp, &cp);
+    fast_sincos(psi, &sp, &cp);
     const double num = v_x * cp - v_y * sp;
     const double dn = 1.0 + kap * n;
     const double inv_dn = 1.0 / dn;
@@ -185,14 +225,7 @@ __device__ constexpr unsigned S_COL_MASK[2][10] = {{0x07u, 0x07u, 0x07u, 0x3Fu, 
 // 12.3 -> 6.3 ms for 8192 x 40 intervals, with MORE instructions executed (the inlined copies were specialised per site).
 static __device__ __noinline__ double nl_atan(double x) { return atan(x); }
 static __device__ __noinline__ double nl_exp(double x) { return exp(x); }
-static __device__ __noinline__ double2 nl_sincos(double x) { double sv, cv; sincos(x, &sv, &cv); return make_double2(sv, cv); }
-// tanh(y) = sign(y) (1 - t) / (1 + t), t = exp(-2 |y|): absolute error ~1e-16 (the relative error grows towards y = 0, where
-// every use multiplies the result by a quantity that vanishes with y)
-__device__ __forceinline__ double tanh_e(double y)
-{
-    const double t = exp(-2.0 * fabs(y));
-    return copysign((1.0 - t) / (1.0 + t), y);
-}
+static __device__ __noinline__ double2 nl_sincos(double x) { double sv, cv; fast_sincos(x, &sv, &cv); return make_double2(sv, cv); }
 static __device__ __noinline__ double nl_tanh(double y) { return tanh_e(y); }
 
 // The two per-wheel functions are calls as well (four uses each per evaluation), with their own transcendentals inlined: a call
@@ -227,7 +260,7 @@ static __device__ __noinline__ PacD nl_pacejka_d(double alpha)
     const double in = Bx - (Bx - t1) * Ea, din = 1.0 - (1.0 - dt1) * Ea;
     const double t2 = atan(in), dt2 = din / fma(in, in, 1.0);
     double sv, cv;
-    sincos(t2 * Ca, &sv, &cv);
+    fast_sincos(t2 * Ca, &sv, &cv);
     PacD r; r.g = sv * Da; r.dg = cv * (Da * Ca * Ba) * dt2;
     return r;
 }
@@ -456,7 +489,7 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
     double dk;
     const double kap = trk.kappa(x[0], dk);
     double sp, cp;
-    sincos(psi, &sp, &cp);
+    fast_sincos(psi, &sp, &cp);
     const double num = v_x * cp - v_y * sp;
     const double inv_dn = 1.0 / (1.0 + kap * n);
     const double s_dot = num * inv_dn;

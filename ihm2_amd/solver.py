@@ -278,6 +278,10 @@ class BatchedOcpSolver:
     def get_residuals(self):
         return self._get(self.lib.ihm2mpc_get_residuals, (self.B, 4))
 
+    def get_qp_residuals(self):
+        """(B, 4) relative KKT residuals of the QP at the returned point (stationarity, dynamics, inequalities, complementarity)."""
+        return self._get(self.lib.ihm2mpc_get_qp_residuals, (self.B, 4))
+
     def get_multipliers(self):
         pi = np.empty((self.B, self.N + 1, NX)); lam = np.empty((self.B, self.N + 1, NLAM))
         _lib.check(self.lib.ihm2mpc_get_multipliers(self._h, _ptr(pi), _ptr(lam)))

@@ -188,6 +188,10 @@ int ihm2mpc_get_u0(ihm2mpc_handle *h, double *u0);              /* (B,2) */
 int ihm2mpc_get_status(ihm2mpc_handle *h, int32_t *status);     /* (B) */
 int ihm2mpc_get_qp_iter(ihm2mpc_handle *h, int32_t *qp_iter);   /* (B) */
 int ihm2mpc_get_residuals(ihm2mpc_handle *h, double *res);      /* (B,4): stat, eq, ineq, comp */
+/* (B,4): inf-norm KKT residuals of the QP (stationarity, dynamics, inequalities, complementarity) at the point the interior-point
+ * iteration returned, each divided by the scale its tolerance is relative to: <= ipm_tol for status 0.  acados: the qp_res of
+ * solver.get_stats("qp_res_*") / print_statistics() */
+int ihm2mpc_get_qp_residuals(ihm2mpc_handle *h, double *res);
 int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam);
 /* slack values the next SQP-mode solve starts from (its line search walks from them to the QP's); NULL = zeros */
 int ihm2mpc_set_slacks(ihm2mpc_handle *h, const double *sl);     /* (B,N+1,28) */

@@ -11,6 +11,11 @@ PASSES = [
     "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU",
     "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM",
 ]
+ICACHE = ["SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES"]
+if os.environ.get("PMC_SET") == "icache":        # instruction-cache pass only
+    PASSES = ICACHE
+elif os.environ.get("PMC_SET") == "all":
+    PASSES = PASSES + ICACHE
 out_dir, out_json = sys.argv[1], sys.argv[2]
 cmd = sys.argv[sys.argv.index("--") + 1:]
 res = collections.defaultdict(dict)
