@@ -54,3 +54,20 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+def test_lean_trig_functions_of_the_models_match_libm(tmp_path):
+    """The models' sincos / tanh (csrc/model.hpp: fast_sincos, tanh_e) restated in C with the same constants and operation order:
+    within 2.5e-16 absolute of libm over +-64 rad / +-200 (tools/probes/check_fast_trig.c)."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tools", "probes", "check_fast_trig.c")
+    exe = str(tmp_path / "check_fast_trig")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    # the constants in the header are the ones the C check uses
+    hdr = open(os.path.join(ROOT, "ihm2_amd", "csrc", "model.hpp")).read()
+    for c in ("6.36619772367581382433e-01", "1.57079632679489655800e+00", "6.12323399573676603587e-17", "-1.49738490485916983693e-33",
+              "1.58969099521155010221e-10", "-1.13596475577881948265e-11"):
+        assert c in hdr and c in open(src).read()

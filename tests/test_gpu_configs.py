@@ -171,6 +171,9 @@ def test_config1_full_size_properties(track):
     assert 5 <= h["qp_iter"].mean() <= 15
     _check_iterate(s, ocp, B, 1.0)
     assert np.all(np.isfinite(s.get_residuals()))
+    # the QPs' own KKT residuals at the returned points: every status-0 solve is inside the interior-point tolerance (relative 1e-6)
+    q = s.get_qp_residuals()
+    assert q.shape == (B, 4) and np.all(q >= 0.0) and np.all(q <= ocp.solver_options.qp_tol)
 
 
 @pytest.mark.parametrize("model,frac", [("fdyn6u", 0.85), ("fdyn6", 0.03)])
