@@ -405,9 +405,11 @@ def main_config2(args):
     B = args.batch if args.batch != 1024 else 8192
     steps, warmup = min(args.steps, 50), min(args.warmup, 10)
     var = {}
-    for model, kw in (("fdyn6", dict(track_rows="soft")), ("fdyn6u", dict(terminal_bounds="stage", track_rows="soft", recover=True))):
+    for name, model, kw in (("fdyn6", "fdyn6", dict(track_rows="soft")),
+                            ("fdyn6u", "fdyn6u", dict(terminal_bounds="stage", track_rows="soft", recover=True)),
+                            ("fdyn6u_irk", "fdyn6u", dict(terminal_bounds="stage", track_rows="soft", recover=True, integrator="IRK"))):
         r = rti_throughput(model=model, B=B, steps=steps, warmup=warmup, **kw)
-        var[model] = {k: r[k] for k in ("solves_per_s", "ms_per_step", "linearize_ms", "qp_ms", "ok_fraction", "status", "qp_iter_mean", "terminal_bounds", "recover")}
+        var[name] = {k: r[k] for k in ("solves_per_s", "ms_per_step", "linearize_ms", "qp_ms", "ok_fraction", "status", "qp_iter_mean", "terminal_bounds", "recover")}
     r = var["fdyn6"]
     print(json.dumps({
         "metric": "NMPC RTI solves/s (batch), N=40, nx=8 (6-DOF dynamic bicycle, Pacejka), fdyn6 + soft track rows",
@@ -419,7 +421,8 @@ def main_config2(args):
         "success_fraction": r["ok_fraction"],
         "variants": var,
         "note": "value = the model as written; its QPs are mostly infeasible (open-loop unstable, DESIGN.md section 2). variants.fdyn6u = "
-                "un-crossed slip angles (named deviation), stage terminal box, re-initialisation of failed instances"}))
+                "un-crossed slip angles (named deviation), stage terminal box, re-initialisation of failed instances; variants.fdyn6u_irk = the same "
+                "with the reference's live integrator (python/main.py:234-236: IRK, 4 Gauss-Legendre stages, 1 step) instead of RK4 x 25"}))
 
 
 if __name__ == "__main__":

@@ -803,7 +803,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         // the QP's own KKT residuals where the iteration stopped, relative to the scales its tolerance is taken against
         // (stationarity, dynamics, inequalities, complementarity: <= ipm_tol each for status 0)
         double *q = a.qp_res + (size_t)b * 4;
-        q[0] = res_g / sg; q[1] = res_b / sb; q[2] = res_d / sb; q[3] = res_m / sg;
+        q[0] = res_g / tol_g * a.tol; q[1] = res_b / tol_b * a.tol; q[2] = res_d / tol_d * a.tol; q[3] = res_m / tol_m * a.tol;      // tol_x = tol * scale_x
     }
 }
 

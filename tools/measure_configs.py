@@ -21,12 +21,14 @@ from ihm2_amd.track import track_table  # noqa: E402
 
 
 def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",), terminal_bounds="reference", track_rows=None, recover=False, host_state=False,
-                   sqp=None, persistent=False):
+                   sqp=None, persistent=False, integrator="ERK"):
     plans = [track_table(t) for t in tracks]
     mdl = O.get_acados_model_from_explicit_dynamics("ihm2_" + model, {"fkin6": O.fkin6_model, "fdyn6": O.fdyn6_model, "fdyn6u": O.fdyn6u_model}[model], 8, 2, 3000)
     ocp = O.get_acados_ocp(mdl, 40, 2.0, 31.0, 500.0, 0.5, 1e6, 1.0)
     ocp.cost.W, ocp.cost.W_e = O.default_weights()
     ocp.solver_options.tf = 2.0
+    if integrator == "IRK":     # python/main.py:234-236: IRK, 4 Gauss-Legendre stages, one step per shooting interval
+        ocp.solver_options.integrator_type, ocp.solver_options.sim_method_num_steps = "IRK", 1
     if sqp is not None:         # the live options of python/main.py:230-237: "SQP", max_iter 2, "MERIT_BACKTRACKING"
         ocp.solver_options.nlp_solver_type, ocp.solver_options.nlp_solver_max_iter, ocp.solver_options.globalization = "SQP", 2, sqp
     if terminal_bounds == "stage":      # see IHM2Controller(terminal_bounds=...): quirk Q1
@@ -83,7 +85,7 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=("fsds_competition_1",),
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
     out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, sqp=sqp,
-               persistent=persistent, steps=steps, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+               persistent=persistent, integrator=integrator, steps=steps, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
                qp_ms=tq / steps, ok_fraction=n_ok / (B * steps), status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
     if sqp:
@@ -130,6 +132,10 @@ if __name__ == "__main__":
                    (rti_throughput, dict(model="fdyn6u", B=8192, track_rows="soft")),
                    (rti_throughput, dict(model="fdyn6u", B=8192, terminal_bounds="stage", track_rows="soft", recover=True)),
                    (rti_throughput, dict(model="fdyn6u", B=8192, tracks=all_tracks, terminal_bounds="stage", track_rows="soft", recover=True)),
+                   # the reference's live integrator (python/main.py:234-236): IRK, 4 Gauss-Legendre stages, one step per interval
+                   (rti_throughput, dict(model="fkin6", B=1024, integrator="IRK")),
+                   (rti_throughput, dict(model="fkin6", B=8192, integrator="IRK")),
+                   (rti_throughput, dict(model="fdyn6u", B=8192, terminal_bounds="stage", track_rows="soft", recover=True, integrator="IRK")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0))),
                    (closed_loop_config5, dict(B=4096, steps=200, device_loop=True)),
