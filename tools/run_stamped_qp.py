@@ -17,7 +17,17 @@ from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 if __name__ == "__main__":
     B = 1024
     ocp, track = bench.build_problem(B)
-    s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    kw = {}
+    if "--soft" in sys.argv:      # soft nonlinear track rows 100 / 100: the <8,3,1,1> instantiation (build with STAMP_SOFT=1)
+        import numpy as np
+        ocp.model.con_h_expr = "track"
+        c = ocp.constraints
+        c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+        c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+        ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+        ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+        kw["track_widths"] = np.array([[track.right_widths.min(), track.left_widths.min()]])
+    s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, **kw)
     s.set_x0(bench.sample_x0(track, B, seed=20240607)); s.init_guess()
     for _ in range(12):          # the stamped launcher prints the sections of its first launches to stderr
         s.step(bench.S_TARGET, model=0, M_sim=bench.M_SUB)
