@@ -75,6 +75,7 @@ SYMBOLS = {
     "ihm2mpc_get_u0": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_status": (C.c_int, [_H, c_int32_p]),
     "ihm2mpc_get_qp_iter": (C.c_int, [_H, c_int32_p]),
+    "ihm2mpc_sim_step_dyn10": (C.c_int, [_H, C.c_int32, c_double_p, c_double_p, c_double_p]),
     "ihm2mpc_get_residuals": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_qp_residuals": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_multipliers": (C.c_int, [_H, c_double_p, c_double_p]),

@@ -199,7 +199,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
@@ -942,6 +942,21 @@ int ihm2mpc_sim_step_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, doubl
     ihm2_launch_sim_cart(h, model, M_sim, dt_sim, n_steps, v_dyn, xs, us, xn, h->stream);
     HIP_TRY(hipGetLastError());
     return download(h, xn, x_next, NX);
+}
+
+int ihm2mpc_sim_step_dyn10(ihm2mpc_handle *h, int32_t M_sim, const double *x, const double *u, double *x_next)
+{
+    CHECK_H(h);
+    if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
+    if (!x || !u || !x_next) return fail("null argument");
+    if (M_sim < 1) return fail("M_sim must be >= 1");
+    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the torque lags (t_T = 1e-3 s): use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
+    if (!h->dyn10) { HIP_TRY(hipMalloc((void **)&h->dyn10, (size_t)h->B * 35 * sizeof(double))); }
+    double *xs = h->dyn10, *us = h->dyn10 + (size_t)h->B * 15, *xn = h->dyn10 + (size_t)h->B * 20;
+    if (upload(h, x, xs, 15) || upload(h, u, us, 5)) return -1;
+    ihm2_launch_sim_dyn10(h, M_sim, xs, us, xn, h->stream);
+    HIP_TRY(hipGetLastError());
+    return download(h, xn, x_next, 15);
 }
 
 int ihm2mpc_project(ihm2mpc_handle *h, const double *x_cart, double *s_guess, double s_tol, double *x_frenet)

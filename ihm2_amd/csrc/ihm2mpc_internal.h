@@ -78,6 +78,7 @@ struct ihm2mpc_handle {
     double *lam;    // (B,NS,28)
     double *slk;    // (B,NS,28) slack values of the soft sides after the last QP (0 for hard sides)
     double *res;    // (B,4)
+    double *dyn10;  // (B,35) staging of the fdyn10 plant: x (15), u (5), x_next (15); allocated on first use
     double *qp_res; // (B,4) KKT residuals of the QP at its returned point, relative to the scales of its tolerances
     int32_t *status, *qp_iter;   // (B)
     int32_t *active;             // (B) plant mask of the device-resident closed loop (nullptr-equivalent while !active_set)
@@ -118,6 +119,7 @@ struct ihm2mpc_handle {
 // --- launchers (each defined in one .hip file) ---
 // mode: bit 0 = reference ramp (needs x0), bit 1 = warm-start shift
 void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream);
+void ihm2_launch_sim_dyn10(ihm2mpc_handle *h, int M, const double *x, const double *u, double *xn, hipStream_t stream);
 void ihm2_launch_wrap_lap(ihm2mpc_handle *h);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);

@@ -85,6 +85,102 @@ __device__ inline void dyn6_rhs(const double (&x)[8], double u_T, double u_delta
     f[7] = (u_delta - delta) * (1.0 / k_tdelta);
 }
 
+// fdyn10 (python/models.py:609-801): 15 states (s, n, psi, v_x, v_y, r, four wheel speeds, four wheel torques, delta), 5 inputs.  The
+// reference writes it as an implicit residual; the normal loads are affine in (a_x, a_y) and the tyre forces are normal load x Pacejka
+// coefficient, so m a = F is a 2 x 2 linear system (as for dyn6 above).  Wheel order FL, FR, RL, RR.
+constexpr double k_b1s = -6.75e-6, k_b2s = 1.35e-1, k_b3s = 1.2e-3, k_c1s = 1.86, k_d1s = 1.12e-4, k_d2s = 1.57, k_e1s = -5.38e-6, k_e2s = 1.11e-2, k_e3s = -4.26;
+constexpr double k_Rw = 0.20809, k_Iw = 0.3, k_kd = 0.17, k_ks = 15.0;
+__device__ inline void fdyn10_rhs(const double (&x)[15], const double (&u)[5], TrackSeg &trk, double (&f)[15])
+{
+    const double n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], delta = x[14];
+    const double W0 = k_static_weight;
+    const double BCDs = (k_b1s * W0 * W0 + k_b2s * W0) * exp(-k_b3s * W0), Cs = k_c1s, Ds = k_d1s * W0 + k_d2s, Es = k_e1s * W0 * W0 + k_e2s * W0 + k_e3s;
+    const double Bs = BCDs / (Cs * Ds);
+    double sd, cd;
+    fast_sincos(delta, &sd, &cd);
+    const double F_drag = -(k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x) * tanh_e(1000.0 * v_x);
+    const double base = W0 + 0.25 * (0.5 * k_Cdown * v_x * v_x);
+    const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track, hx = 0.5 * k_axle_track;
+    const double vxL = v_x - hx * r, vxR = v_x + hx * r, vyF = v_y + k_lF * r, vyR = v_y - k_lR * r;
+    const double v_lon[4] = {cd * vxL + sd * vyF, cd * vxR + sd * vyF, vxL, vxR};
+    const double v_lat[4] = {-sd * vxL + cd * vyF, -sd * vxR + cd * vyF, vyR, vyR};
+    double cs[4], fx[4], fy[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const double va = tanh_e(10.0 * v_lon[w]) * v_lon[w] + 1e-6 * exp(-(v_lon[w] * v_lon[w]));
+        const double cl = lat_pacejka_t(atan2(v_lat[w], va));
+        const double bs = Bs * (x[6 + w] * k_Rw / va - 1.0);
+        cs[w] = Ds * sin(Cs * atan(bs - Es * (bs - atan(bs))));
+        // body-frame force per unit of normal load N_w = -F_z,w:  F_lon = N cs, F_lat = -N cl
+        if (w < 2) { fx[w] = cd * cs[w] + sd * cl; fy[w] = sd * cs[w] - cd * cl; }
+        else { fx[w] = cs[w]; fy[w] = -cl; }
+    }
+    // N_w = base + sx_w cx a_x + sy_w cy a_y, sx = (-,-,+,+), sy = (+,-,+,-)
+    const double Sfx = fx[0] + fx[1] + fx[2] + fx[3], Sfy = fy[0] + fy[1] + fy[2] + fy[3];
+    const double Sxx = -fx[0] - fx[1] + fx[2] + fx[3], Sxy = fx[0] - fx[1] + fx[2] - fx[3];
+    const double Syx = -fy[0] - fy[1] + fy[2] + fy[3], Syy = fy[0] - fy[1] + fy[2] - fy[3];
+    const double a11 = k_m - cx * Sxx, a12 = -cy * Sxy, a21 = -cx * Syx, a22 = k_m - cy * Syy;
+    const double b1 = F_drag + base * Sfx, b2 = base * Sfy, det = a11 * a22 - a12 * a21;
+    const double a_x = (b1 * a22 - a12 * b2) / det, a_y = (a11 * b2 - a21 * b1) / det;
+    const double lx = cx * a_x, ly = cy * a_y;
+    const double Nw[4] = {base - lx + ly, base - lx - ly, base + lx + ly, base + lx - ly};
+    double dk;
+    const double kap = trk.kappa(x[0], dk);
+    double sp, cp;
+    fast_sincos(psi, &sp, &cp);
+    const double s_dot = (v_x * cp - v_y * sp) / (1.0 + kap * n);
+    f[0] = s_dot;
+    f[1] = v_x * sp + v_y * cp;
+    f[2] = r - kap * s_dot;
+    f[3] = a_x + v_y * r;
+    f[4] = a_y - v_x * r;
+    f[5] = ((Nw[1] * fx[1] - Nw[0] * fx[0]) * hx + (Nw[1] * fy[1] + Nw[0] * fy[0]) * k_lF + (Nw[3] * fx[3] - Nw[2] * fx[2]) * hx
+            - (Nw[3] * fy[3] + Nw[2] * fy[2]) * k_lR) * (1.0 / k_Iz);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        f[6 + w] = (x[10 + w] - (k_kd * x[6 + w] + k_ks + k_Rw * (Nw[w] * cs[w]))) * (1.0 / k_Iw);
+        f[10 + w] = (u[w] - x[10 + w]) * (1.0 / k_tT);
+    }
+    f[14] = (u[4] - delta) * (1.0 / k_tdelta);
+}
+
+// plant step of the 15-state model: RK4 x M over dt; one lane per instance
+__global__ __launch_bounds__(64) void k_sim_dyn10(int B, int M, double dt, int nknots, const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
+                                                  const int32_t *__restrict__ track_id, const double *xs, const double *__restrict__ us, double *xn)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double x[15], u[5];
+#pragma unroll
+    for (int i = 0; i < 15; i++) x[i] = xs[(size_t)b * 15 + i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) u[i] = us[(size_t)b * 5 + i];
+    const int tid = track_id[b];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
+    const double h = dt / M;
+    for (int m = 0; m < M; m++) {
+        double xacc[15], K[15];
+#pragma unroll
+        for (int i = 0; i < 15; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+#pragma unroll 1
+        for (int st = 0; st < 4; st++) {
+            const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
+            const double wh = (st == 0 || st == 3) ? h * (1.0 / 6.0) : h * (2.0 / 6.0);
+            double X[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) X[i] = fma(ah, K[i], x[i]);
+            fdyn10_rhs(X, u, trk, K);
+#pragma unroll
+            for (int i = 0; i < 15; i++) xacc[i] = fma(wh, K[i], xacc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 15; i++) x[i] = xacc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 15; i++) xn[(size_t)b * 15 + i] = x[i];
+}
+
 // n_steps plant steps of length dt (each RK4 x M); model 3 = kin6, 4 = dyn6, -3 = the node's speed switch + no reversing
 __global__ __launch_bounds__(64) void k_sim_cart(int B, int model, int M, double dt, int n_steps, double v_dyn, const double *xs,
                                                  const double *__restrict__ us, double *xn)
@@ -202,6 +298,11 @@ void ihm2_launch_sim_cart(ihm2mpc_handle *h, int model, int M, double dt, int n_
                           double *xn, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_sim_cart, dim3((h->B + 63) / 64), dim3(64), 0, stream, h->B, model, M, dt, n_steps, v_dyn, x, u, xn);
+}
+
+void ihm2_launch_sim_dyn10(ihm2mpc_handle *h, int M, const double *x, const double *u, double *xn, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_sim_dyn10, dim3((h->B + 63) / 64), dim3(64), 0, stream, h->B, M, h->cfg.dt, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn);
 }
 
 void ihm2_launch_project(ihm2mpc_handle *h, double s_tol, const double *xc, double *s_guess, double *xf, hipStream_t stream)

@@ -20,7 +20,8 @@ INF = float("inf")
 MODEL_FKIN6 = 0
 MODEL_FDYN6 = 1
 MODEL_FDYN6U = 2     # fdyn6 with un-crossed slip angles (include/ihm2mpc.h: IHM2MPC_MODEL_FDYN6U); not in the reference
-_MODEL_IDS = {"fkin6": MODEL_FKIN6, "fdyn6": MODEL_FDYN6, "fdyn6u": MODEL_FDYN6U}
+MODEL_FDYN10 = 10      # plant only (15 states, 5 inputs): no OCP model id in the C ABI, its own entry point ihm2mpc_sim_step_dyn10
+_MODEL_IDS = {"fkin6": MODEL_FKIN6, "fdyn6": MODEL_FDYN6, "fdyn6u": MODEL_FDYN6U, "fdyn10": MODEL_FDYN10}
 INTEG_RK4 = 0
 INTEG_IRK_GL4 = 1      # IRK, GAUSS_LEGENDRE, 4 stages: acados' default collocation (python/main.py:234-236)
 INTEG_IRK_RADAU4 = 2   # IRK, GAUSS_RADAU_IIA, 4 stages (python/main.py:395-400, python/sim.py:28-33)
@@ -69,6 +70,12 @@ def fdyn6u_model(xdot=None, x=None, u=None, p=None):
     """``fdyn6_model`` with every wheel's lateral force on its own slip angle.  The reference crosses them
     (``python/models.py:543-546``), which makes the model open-loop unstable; this variant is a named deviation."""
     return "fdyn6u"
+
+
+def fdyn10_model(xdot=None, x=None, u=None, p=None):
+    """Frenet model with wheel speeds: 15 states, 5 inputs (``python/models.py:609-801``) -- a PLANT of the MiL loop
+    (``python/main.py:490-502``), never an OCP model."""
+    return "fdyn10"
 
 
 @dataclass
@@ -329,6 +336,8 @@ class OcpData:
     def from_ocp(ocp: AcadosOcp) -> "OcpData":
         o, d, c = ocp.solver_options, ocp.dims, ocp.constraints
         N = d.N
+        if ocp.model.kind == "fdyn10":
+            raise ValueError("fdyn10 is a plant model (python/main.py:490-502): it has no OCP in the reference and none here")
         if (d.nx, d.nu, d.ny, d.ny_e) != (NX, NU, NY, NX):
             raise ValueError("this implementation is specialised to nx=8, nu=2, ny=12, ny_e=8")
         if ocp.cost.cost_type != "LINEAR_LS" or ocp.cost.cost_type_e != "LINEAR_LS":

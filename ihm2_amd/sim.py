@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .ocp import NU, NX, AcadosModel, AcadosOcp, AcadosOcpOptions, default_weights, get_acados_ocp
+from .ocp import NU, NX, AcadosModel, AcadosOcp, AcadosOcpOptions, default_weights, fkin6_model, get_acados_model_from_explicit_dynamics, get_acados_ocp
 
 
 @dataclass
@@ -41,7 +41,7 @@ class AcadosSim:
 
 
 class AcadosSimSolver:
-    """``acados_template.AcadosSimSolver`` for the models of this build (``fkin6``, ``fdyn6``, ``fdyn6u``), batched."""
+    """``acados_template.AcadosSimSolver`` for the models of this build (``fkin6``, ``fdyn6``, ``fdyn6u``; ``fdyn10`` with RK4), batched."""
 
     def __init__(self, sim: AcadosSim, json_file: str | None = None, verbose: bool = False, batch_size: int = 1, device: int = 0, **kwargs):
         o = sim.solver_options
@@ -53,9 +53,15 @@ class AcadosSimSolver:
             raise ValueError("the IRK integrator runs acados' default of 3 Newton iterations per step")
         self.sim, self.B, self.device = sim, int(batch_size), int(device)
         self.model_id = sim.model.model_id
+        # fdyn10 (python/models.py:609-801; the DYN10 plant of python/main.py:490-502): 15 states, 5 inputs, explicit RK4 only
+        self.dyn10 = sim.model.kind == "fdyn10"
+        if self.dyn10 and o.integrator_type != "ERK":
+            raise ValueError('fdyn10 is integrated with RK4 x num_steps here (integrator_type = "ERK"); the reference uses Radau IIA x 100: '
+                             "the implicit integrators of this build are written for the 8-state models")
+        self.nx, self.nu = (15, 5) if self.dyn10 else (NX, NU)
         self._T = float(o.T)
         self._p = None if sim.parameter_values is None else np.asarray(sim.parameter_values, dtype=float).ravel()
-        self._x = np.zeros((self.B, NX)); self._u = np.zeros((self.B, NU)); self._xn = np.zeros((self.B, NX))
+        self._x = np.zeros((self.B, self.nx)); self._u = np.zeros((self.B, self.nu)); self._xn = np.zeros((self.B, self.nx))
         self._time = 0.0
         self._solver = None
 
@@ -69,11 +75,14 @@ class AcadosSimSolver:
         if p is None or p.size < 4 or p.size % 2 or not np.all(np.diff(p[: p.size // 2]) > 0):
             raise ValueError('set("p", [s_ref; kappa_ref]) first: the track table the models interpolate (python/main.py:432-435)')
         o = self.sim.solver_options
-        ocp: AcadosOcp = get_acados_ocp(self.sim.model, 2, 1e3, 1e3, 1e6, 10.0, 1e9, 1e9)      # a carrier for the plant: never solved
+        carrier = get_acados_model_from_explicit_dynamics("carrier", fkin6_model, NX, NU, p.size) if self.dyn10 else self.sim.model
+        ocp: AcadosOcp = get_acados_ocp(carrier, 2, 1e3, 1e3, 1e6, 10.0, 1e9, 1e9)      # a carrier for the plant: never solved
         ocp.cost.W, ocp.cost.W_e = default_weights()
         so: AcadosOcpOptions = ocp.solver_options
         so.tf = 2 * self._T
         so.sim_integrator_type, so.sim_collocation_type = o.integrator_type, o.collocation_type
+        if self.dyn10:
+            so.sim_method_num_steps = 25         # of the (unused) carrier OCP
         n = p.size // 2
         self._solver = BatchedOcpSolver(ocp, self.B, p[:n], p[n:], device=self.device)
         return self._solver
@@ -81,9 +90,9 @@ class AcadosSimSolver:
     def set(self, field_: str, value) -> None:
         v = np.asarray(value, dtype=float)
         if field_ == "x":
-            self._x[...] = v.reshape(-1, NX) if v.ndim > 1 else v
+            self._x[...] = v.reshape(-1, self.nx) if v.ndim > 1 else v
         elif field_ == "u":
-            self._u[...] = v.reshape(-1, NU) if v.ndim > 1 else v
+            self._u[...] = v.reshape(-1, self.nu) if v.ndim > 1 else v
         elif field_ == "p":
             self._p = v.ravel().copy()
             if self._solver is not None:
@@ -99,7 +108,10 @@ class AcadosSimSolver:
         """One integration over ``T``; status 0, or 1 if a state came back non-finite (acados: ACADOS_FAILURE)."""
         s = self._backend()
         t0 = time.perf_counter()
-        self._xn = s.sim_step(self._x, self._u, model=self.model_id, M_sim=int(self.sim.solver_options.num_steps))
+        if self.dyn10:
+            self._xn = s.sim_step_dyn10(self._x, self._u, M_sim=int(self.sim.solver_options.num_steps))
+        else:
+            self._xn = s.sim_step(self._x, self._u, model=self.model_id, M_sim=int(self.sim.solver_options.num_steps))
         self._time = time.perf_counter() - t0
         return 0 if np.all(np.isfinite(self._xn)) else 1
 

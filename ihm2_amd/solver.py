@@ -278,6 +278,12 @@ class BatchedOcpSolver:
     def get_residuals(self):
         return self._get(self.lib.ihm2mpc_get_residuals, (self.B, 4))
 
+    def sim_step_dyn10(self, x, u, M_sim: int = 100):
+        """Plant step of the 15-state model ``fdyn10`` (python/models.py:609-801): ``x`` (B, 15), ``u`` (B, 5) -> (B, 15)."""
+        xn = np.empty((self.B, 15))
+        _lib.check(self.lib.ihm2mpc_sim_step_dyn10(self._h, int(M_sim), _ptr(_f64(x, (self.B, 15), "x")), _ptr(_f64(u, (self.B, 5), "u")), _ptr(xn)))
+        return xn
+
     def get_qp_residuals(self):
         """(B, 4) relative KKT residuals of the QP at the returned point (stationarity, dynamics, inequalities, complementarity)."""
         return self._get(self.lib.ihm2mpc_get_qp_residuals, (self.B, 4))

@@ -185,6 +185,11 @@ void orc_cart_to_frenet(int B, int ntracks, int nk, const double *s_ref, const d
                         double *x_frenet);
 void orc_sim_step_cart(int B, int model, int M, double dt, double v_dyn, const double *x, const double *u, double *xnext);
 
+/* --- fdyn10 (ihm2_oracle_dyn10.c): the 15-state Frenet plant with wheel speeds, python/models.py:609-801 --- */
+void orc_f_dyn10(const double *x, const double *u, const double *s_ref, const double *kappa_ref, int nknots, double *xdot);
+void orc_sim_step_dyn10(int B, int M, double dt, const double *x, const double *u, const double *s_ref, const double *kappa_ref, int nknots,
+                        double *xnext);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,3 +270,72 @@ def jac_complex_step(f, x, u, s_ref, kappa_ref, h=1e-30):
             uc[j - 8] += 1j * h
         J[:, j] = np.imag(f(xc, uc, s_ref, kappa_ref)) / h
     return J
+
+
+# ---- fdyn10: 15-state Frenet model with wheel speeds (python/models.py:609-801), IMPLICIT residual as the reference writes it ----
+b1s, b2s, b3s, c1s, d1s, d2s, e1s, e2s, e3s = -6.75e-6, 1.35e-1, 1.2e-3, 1.86, 1.12e-4, 1.57, -5.38e-6, 1.11e-2, -4.26
+BCDs = (b1s * static_weight**2 + b2s * static_weight) * np.exp(-b3s * static_weight)
+Cs = c1s
+Ds = d1s * static_weight + d2s
+Es = e1s * static_weight**2 + e2s * static_weight + e3s
+Bs = BCDs / (Cs * Ds)
+R_w, I_w, k_d, k_s = 0.20809, 0.3, 0.17, 15.0
+
+
+def lon_pacejka(s):
+    return Ds * np.sin(Cs * np.arctan(Bs * s - Es * (Bs * s - np.arctan(Bs * s))))
+
+
+def fdyn10_residual(xdot, x, u, s_ref, kappa_ref):
+    """Residual vector in the order of python/models.py:747-801 (zero when xdot is the model's derivative)."""
+    s, n, psi, v_x, v_y, r, o_FL, o_FR, o_RL, o_RR, tau_FL, tau_FR, tau_RL, tau_RR, delta = x
+    u_FL, u_FR, u_RL, u_RR, u_delta = u
+    (s_dot, n_dot, psi_dot, v_x_dot, v_y_dot, r_dot, o_FL_dot, o_FR_dot, o_RL_dot, o_RR_dot,
+     tau_FL_dot, tau_FR_dot, tau_RL_dot, tau_RR_dot, delta_dot) = xdot
+    a_x = v_x_dot - v_y * r
+    a_y = v_y_dot + v_x * r
+    F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * np.tanh(1000 * v_x)
+    F_downforce = 0.5 * C_downforce * v_x * v_x
+    lon_wt = 0.5 * m * a_x * z_CG / wheelbase
+    lat_wt = 0.5 * m * a_y * z_CG / front_axle_track
+    F_z_FL = -(static_weight - lon_wt + lat_wt + 0.25 * F_downforce)
+    F_z_FR = -(static_weight - lon_wt - lat_wt + 0.25 * F_downforce)
+    F_z_RL = -(static_weight + lon_wt + lat_wt + 0.25 * F_downforce)
+    F_z_RR = -(static_weight + lon_wt - lat_wt + 0.25 * F_downforce)
+    v_x_FL = v_x - 0.5 * front_axle_track * r
+    v_x_FR = v_x + 0.5 * front_axle_track * r
+    v_y_FL = v_y_FR = v_y + l_F * r
+    cd, sd = np.cos(delta), np.sin(delta)
+    v_lon_FL, v_lon_FR = cd * v_x_FL + sd * v_y_FL, cd * v_x_FR + sd * v_y_FR
+    v_lat_FL, v_lat_FR = -sd * v_x_FL + cd * v_y_FL, -sd * v_x_FR + cd * v_y_FR
+    v_lon_RL, v_lon_RR = v_x - 0.5 * rear_axle_track * r, v_x + 0.5 * rear_axle_track * r
+    v_lat_RL = v_lat_RR = v_y - l_R * r
+    sa = [smooth_abs_nonzero(v) for v in (v_lon_FL, v_lon_FR, v_lon_RL, v_lon_RR)]
+    alpha = [np.arctan2(vl, a) for vl, a in zip((v_lat_FL, v_lat_FR, v_lat_RL, v_lat_RR), sa)]
+    Fz = (F_z_FL, F_z_FR, F_z_RL, F_z_RR)
+    F_lat = [fz * lat_pacejka(al) for fz, al in zip(Fz, alpha)]
+    slip = [o * R_w / a - 1.0 for o, a in zip((o_FL, o_FR, o_RL, o_RR), sa)]
+    F_lon = [-fz * lon_pacejka(sl) for fz, sl in zip(Fz, slip)]
+    kap = kappa_interp(s, s_ref, kappa_ref)
+    s_dot_expr = (v_x * np.cos(psi) - v_y * np.sin(psi)) / (1 + kap * n)
+    return np.array([
+        s_dot - s_dot_expr,
+        n_dot - (v_x * np.sin(psi) + v_y * np.cos(psi)),
+        psi_dot - (r - kap * s_dot_expr),
+        m * a_x - (F_drag + cd * (F_lon[0] + F_lon[1]) - sd * (F_lat[0] + F_lat[1]) + F_lon[2] + F_lon[3]),
+        m * a_y - (sd * (F_lon[0] + F_lon[1]) + cd * (F_lat[0] + F_lat[1]) + F_lat[2] + F_lat[3]),
+        I_z * r_dot - (
+            (F_lon[1] * cd - F_lat[1] * sd) * front_axle_track / 2 + (F_lon[1] * sd + F_lat[1] * cd) * l_F
+            - (F_lon[0] * cd - F_lat[0] * sd) * front_axle_track / 2 + (F_lon[0] * sd + F_lat[0] * cd) * l_F
+            + F_lon[3] * rear_axle_track / 2 - F_lat[3] * l_R - F_lon[2] * rear_axle_track / 2 - F_lat[2] * l_R
+        ),
+        I_w * o_FL_dot - (tau_FL - (k_d * o_FL + k_s + R_w * F_lon[0])),
+        I_w * o_FR_dot - (tau_FR - (k_d * o_FR + k_s + R_w * F_lon[1])),
+        I_w * o_RL_dot - (tau_RL - (k_d * o_RL + k_s + R_w * F_lon[2])),
+        I_w * o_RR_dot - (tau_RR - (k_d * o_RR + k_s + R_w * F_lon[3])),
+        tau_FL_dot - (u_FL - tau_FL) / t_T,
+        tau_FR_dot - (u_FR - tau_FR) / t_T,
+        tau_RL_dot - (u_RL - tau_RL) / t_T,
+        tau_RR_dot - (u_RR - tau_RR) / t_T,
+        delta_dot - (u_delta - delta) / t_delta,
+    ])

@@ -159,6 +159,23 @@ def sim_step_cart(x, u, model, M, dt=0.05, v_dyn=3.0):
     return xn
 
 
+def f_dyn10(x, u, s_ref, kappa_ref):
+    """Explicit ``fdyn10`` derivative (python/models.py:609-801 solved for xdot); x (B,15), u (B,5)."""
+    x, _ = _d(np.atleast_2d(x)); u, _ = _d(np.atleast_2d(u)); sr, srp = _d(s_ref); kr, krp = _d(kappa_ref)
+    out = np.zeros_like(x)
+    for b in range(x.shape[0]):
+        lib().orc_f_dyn10(x[b].ctypes.data_as(_dp), u[b].ctypes.data_as(_dp), srp, krp, C.c_int(sr.size), out[b].ctypes.data_as(_dp))
+    return out
+
+
+def sim_step_dyn10(x, u, s_ref, kappa_ref, M, dt=0.05):
+    """``fdyn10`` plant step, RK4 x M over dt; x (B,15), u (B,5)."""
+    x, xp = _d(np.atleast_2d(x)); u, up = _d(np.atleast_2d(u)); sr, srp = _d(s_ref); kr, krp = _d(kappa_ref)
+    xn = np.zeros_like(x)
+    lib().orc_sim_step_dyn10(C.c_int(x.shape[0]), C.c_int(M), C.c_double(dt), xp, up, srp, krp, C.c_int(sr.size), xn.ctypes.data_as(_dp))
+    return xn
+
+
 class OracleProblem:
     """Holds the arrays of an ``orc_problem`` alive.  ``desc`` is a plain dict of numpy arrays and
     scalars (the product's ``OcpData.as_dict()`` produces exactly this)."""
