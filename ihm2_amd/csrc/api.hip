@@ -244,6 +244,50 @@ int ihm2mpc_set_tracks(ihm2mpc_handle *h, const double *s_ref, const double *kap
     return 0;
 }
 
+int ihm2mpc_build_tracks(ihm2mpc_handle *h, int32_t max_seg, const int32_t *nseg, const double *coeffs_X, const double *coeffs_Y)
+{
+    CHECK_H(h);
+    if (!nseg || !coeffs_X || !coeffs_Y) return fail("null argument");
+    if (h->cfg.nknots % 3 != 0) return fail("nknots = %d is not three laps of samples", h->cfg.nknots);
+    if (max_seg < 2) return fail("max_seg must be >= 2");
+    for (int t = 0; t < h->cfg.ntracks; t++)
+        if (nseg[t] < 2 || nseg[t] > max_seg) return fail("track %d has %d spline segments (2 .. max_seg = %d)", t, nseg[t], max_seg);
+    const size_t nc = (size_t)h->cfg.ntracks * max_seg;
+    double *dev = nullptr;
+    int32_t *dseg = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, nc * 9 * sizeof(double)));
+    if (hipMalloc((void **)&dseg, h->cfg.ntracks * sizeof(int32_t)) != hipSuccess) { (void)hipFree(dev); return fail("out of device memory"); }
+    double *cX = dev, *cY = dev + nc * 4, *work = dev + nc * 8;
+    int rc = 0;
+    if (hipMemcpyAsync(cX, coeffs_X, nc * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(cY, coeffs_Y, nc * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(dseg, nseg, h->cfg.ntracks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail("upload of the spline coefficients failed");
+    if (!rc) {
+        ihm2_launch_build_tracks(h, max_seg, dseg, cX, cY, work);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) rc = fail("track-table kernels failed");
+    }
+    (void)hipFree(dev); (void)hipFree(dseg);
+    if (rc) return rc;
+    h->tracks_set = true; h->geometry_set = true;
+    return 0;
+}
+
+int ihm2mpc_get_tracks(ihm2mpc_handle *h, double *s_ref, double *kappa_ref, double *X_ref, double *Y_ref, double *phi_ref)
+{
+    CHECK_H(h);
+    if (!h->tracks_set) return fail("no track tables yet");
+    const size_t n = (size_t)h->cfg.ntracks * h->cfg.nknots * sizeof(double);
+    const double *src[5] = {h->s_ref, h->kappa_ref, h->X_ref, h->Y_ref, h->phi_ref};
+    double *dst[5] = {s_ref, kappa_ref, X_ref, Y_ref, phi_ref};
+    for (int i = 0; i < 5; i++)
+        if (dst[i]) {
+            if (i >= 2 && !h->geometry_set) return fail("ihm2mpc_set_track_geometry / ihm2mpc_build_tracks has not been called");
+            HIP_TRY(hipMemcpyAsync(dst[i], src[i], n, hipMemcpyDeviceToHost, h->stream));
+        }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int ihm2mpc_set_track_id(ihm2mpc_handle *h, const int32_t *track_id)
 {
     CHECK_H(h);

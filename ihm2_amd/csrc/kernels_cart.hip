@@ -292,7 +292,92 @@ __global__ __launch_bounds__(64) void k_project(int B, int nk, double s_tol, con
     s_guess[b] = fmod(s + xc[(size_t)b * 8 + 3] * 0.05, -sr[0]);
 }
 
+// ---- track tables on the device (python/motion_planning.py:139-289, 345-428) ----
+// In: the cubic spline coefficients of every segment of every centre line (the closed-spline fit itself is one small KKT solve per
+// track on the host).  Out: the tables the models and the projection read -- s_ref, kappa_ref, X_ref, Y_ref, phi_ref on nknots = 3 x
+// n_samples knots (three laps side by side).
+__device__ __forceinline__ double poly3(const double *c, double t, int der)
+{
+    if (der == 0) return c[0] + t * (c[1] + t * (c[2] + t * c[3]));
+    if (der == 1) return c[1] + t * (2.0 * c[2] + 3.0 * c[3] * t);
+    return 2.0 * c[2] + 6.0 * c[3] * t;
+}
+// polyline length of a segment on 100 points (compute_spline_interval_lengths): one lane per (track, segment)
+__global__ __launch_bounds__(64) void k_track_seglen(int ntracks, int max_seg, const int32_t *__restrict__ nseg, const double *__restrict__ cX,
+                                                     const double *__restrict__ cY, double *seglen)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= ntracks * max_seg) return;
+    const int t = e / max_seg, j = e - t * max_seg;
+    double len = 0.0;
+    if (j < nseg[t]) {
+        const double *cx = cX + (size_t)e * 4, *cy = cY + (size_t)e * 4;
+        double xp = poly3(cx, 0.0, 0), yp = poly3(cy, 0.0, 0);
+        for (int i = 1; i < 100; i++) {
+            const double tt = (i == 99) ? 1.0 : i * (1.0 / 99.0);
+            const double xq = poly3(cx, tt, 0), yq = poly3(cy, tt, 0);
+            len += hypot(xq - xp, yq - yp);
+            xp = xq; yp = yq;
+        }
+    }
+    seglen[e] = len;
+}
+// cumulative arc length at the segment ends, in place: one lane per track (a few dozen segments)
+__global__ void k_track_cumsum(int ntracks, int max_seg, const int32_t *__restrict__ nseg, double *seglen_to_send)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntracks) return;
+    double acc = 0.0;
+    for (int j = 0; j < nseg[t]; j++) { acc += seglen_to_send[(size_t)t * max_seg + j]; seglen_to_send[(size_t)t * max_seg + j] = acc; }
+}
+// uniformly_sample_spline + get_heading + get_curvature + offline_motion_plan's heading offset + triple_motion_plan_ref:
+// one lane per (track, sample); every lane writes its sample into the three laps
+__global__ __launch_bounds__(64) void k_track_sample(int ntracks, int max_seg, int n_samples, const int32_t *__restrict__ nseg, const double *__restrict__ cX,
+                                                     const double *__restrict__ cY, const double *__restrict__ s_end, double *s_ref, double *kappa_ref,
+                                                     double *X_ref, double *Y_ref, double *phi_ref)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= ntracks * n_samples) return;
+    const int t = e / n_samples, i = e - t * n_samples;
+    const int ns = nseg[t];
+    const double *se = s_end + (size_t)t * max_seg;
+    const double total = se[ns - 1], step = total / n_samples;
+    auto sample = [&](int k, double &X, double &Y, double &phi, double &kap) -> double {
+        const double s = k * step;
+        int idx = 0;
+        while (idx < ns - 1 && !(s < se[idx])) idx++;           // first segment whose end lies beyond s
+        const double s0 = (idx == 0) ? 0.0 : se[idx - 1];
+        const double tt = (s - s0) / (se[idx] - s0);
+        const double *cx = cX + ((size_t)t * max_seg + idx) * 4, *cy = cY + ((size_t)t * max_seg + idx) * 4;
+        X = poly3(cx, tt, 0); Y = poly3(cy, tt, 0);
+        const double xd = poly3(cx, tt, 1), yd = poly3(cy, tt, 1), xdd = poly3(cx, tt, 2), ydd = poly3(cy, tt, 2);
+        const double q = xd * xd + yd * yd;
+        kap = (xd * ydd - yd * xdd) / (q * sqrt(q));
+        phi = atan2(yd, xd) - asin(k_lR * kap);
+        return s;
+    };
+    double X, Y, phi, kap, Xl, Yl, pl, kl, X0, Y0, p0, k0;
+    const double s = sample(i, X, Y, phi, kap);
+    const double s_last = sample(n_samples - 1, Xl, Yl, pl, kl);
+    (void)sample(0, X0, Y0, p0, k0);
+    const double L = s_last + hypot(Xl - X0, Yl - Y0);         // lap length as offline_motion_plan closes it
+    const int nk = 3 * n_samples;
+    for (int lap = 0; lap < 3; lap++) {
+        const size_t o = (size_t)t * nk + (size_t)lap * n_samples + i;
+        s_ref[o] = s + (lap - 1) * L; kappa_ref[o] = kap; X_ref[o] = X; Y_ref[o] = Y; phi_ref[o] = phi;
+    }
+}
+
 }  // namespace
+
+void ihm2_launch_build_tracks(ihm2mpc_handle *h, int max_seg, const int32_t *nseg, const double *cX, const double *cY, double *work)
+{
+    const int nt = h->cfg.ntracks, n_samples = h->cfg.nknots / 3;
+    hipLaunchKernelGGL(k_track_seglen, dim3((nt * max_seg + 63) / 64), dim3(64), 0, h->stream, nt, max_seg, nseg, cX, cY, work);
+    hipLaunchKernelGGL(k_track_cumsum, dim3((nt + 63) / 64), dim3(64), 0, h->stream, nt, max_seg, nseg, work);
+    hipLaunchKernelGGL(k_track_sample, dim3((nt * n_samples + 63) / 64), dim3(64), 0, h->stream, nt, max_seg, n_samples, nseg, cX, cY, work,
+                       h->s_ref, h->kappa_ref, h->X_ref, h->Y_ref, h->phi_ref);
+}
 
 void ihm2_launch_sim_cart(ihm2mpc_handle *h, int model, int M, double dt, int n_steps, double v_dyn, const double *x, const double *u,
                           double *xn, hipStream_t stream)

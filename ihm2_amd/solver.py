@@ -278,6 +278,28 @@ class BatchedOcpSolver:
     def get_residuals(self):
         return self._get(self.lib.ihm2mpc_get_residuals, (self.B, 4))
 
+    def build_tracks(self, coeffs_X, coeffs_Y):
+        """Track tables on the device from the centre lines' spline coefficients (``python/motion_planning.py:139-428``): ``coeffs_X``,
+        ``coeffs_Y`` are lists of ``(nseg_t, 4)`` arrays, one per track (``track.py::fit_spline``).  Replaces ``set_tracks`` +
+        ``set_track_geometry``; ``nknots`` of this solver = 3 x samples per lap."""
+        if len(coeffs_X) != self.ntracks or len(coeffs_Y) != self.ntracks:
+            raise ValueError(f"{self.ntracks} tracks expected")
+        nseg = np.array([len(c) for c in coeffs_X], dtype=np.int32)
+        mx = int(nseg.max())
+        cX = np.zeros((self.ntracks, mx, 4)); cY = np.zeros((self.ntracks, mx, 4))
+        for t in range(self.ntracks):
+            cX[t, :nseg[t]] = coeffs_X[t]; cY[t, :nseg[t]] = coeffs_Y[t]
+        _lib.check(self.lib.ihm2mpc_build_tracks(self._h, mx, nseg.ctypes.data_as(_lib.c_int32_p), _ptr(cX), _ptr(cY)))
+        s_ref = np.empty((self.ntracks, self.nknots)); kappa = np.empty((self.ntracks, self.nknots))
+        _lib.check(self.lib.ihm2mpc_get_tracks(self._h, _ptr(s_ref), _ptr(kappa), None, None, None))
+        self._s_ref, self._kappa_ref = s_ref, kappa          # the host copies the per-instance shim compares "p" against
+
+    def get_tracks(self):
+        """``(s_ref, kappa_ref, X_ref, Y_ref, phi_ref)``, each ``(ntracks, nknots)``, as they are on the device."""
+        out = [np.empty((self.ntracks, self.nknots)) for _ in range(5)]
+        _lib.check(self.lib.ihm2mpc_get_tracks(self._h, *[_ptr(a) for a in out]))
+        return tuple(out)
+
     def sim_step_dyn10(self, x, u, M_sim: int = 100):
         """Plant step of the 15-state model ``fdyn10`` (python/models.py:609-801): ``x`` (B, 15), ``u`` (B, 5) -> (B, 15)."""
         xn = np.empty((self.B, 15))

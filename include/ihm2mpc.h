@@ -115,6 +115,15 @@ int ihm2mpc_get_stream(ihm2mpc_handle *h, void **stream);
 
 /* ---- problem data shared by the whole batch ---- */
 int ihm2mpc_set_tracks(ihm2mpc_handle *h, const double *s_ref, const double *kappa_ref); /* (ntracks,nknots) each */
+/* The same tables (and the centre-line geometry of ihm2mpc_set_track_geometry) built ON THE DEVICE from the cubic spline coefficients of
+ * the centre lines -- python/motion_planning.py:139-289 (segment lengths on 100 points, uniform arc-length resampling, heading, curvature),
+ * :345-399 (offline_motion_plan: heading offset -asin(l_R kappa), lap length) and :402-428 (three laps side by side): nknots = 3 x samples
+ * per lap.  coeffs_X, coeffs_Y: (ntracks, max_seg, 4), segment j of track t in [c0, c1, c2, c3] of X(t) = c0 + c1 t + c2 t^2 + c3 t^3,
+ * t in [0, 1]; nseg (ntracks): segments of each track (the rest of its rows is ignored).  The closed-spline fit that produces the
+ * coefficients (python/motion_planning.py:28-124: one small equality-constrained least-squares problem per track) stays on the host. */
+int ihm2mpc_build_tracks(ihm2mpc_handle *h, int32_t max_seg, const int32_t *nseg, const double *coeffs_X, const double *coeffs_Y);
+/* read the tables back, (ntracks, nknots) each; any pointer may be NULL */
+int ihm2mpc_get_tracks(ihm2mpc_handle *h, double *s_ref, double *kappa_ref, double *X_ref, double *Y_ref, double *phi_ref);
 int ihm2mpc_set_track_id(ihm2mpc_handle *h, const int32_t *track_id);                     /* (B) */
 int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e);           /* (N,12,12), (8,8) */
 /* lbx/ubx (N+1,8) [row 0 unused], lbu/ubu (N,2), C (N,2,8), D (N,2,2), lg/ug (N,2); +-inf = absent */

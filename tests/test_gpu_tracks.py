@@ -1,0 +1,50 @@
+"""SURVEY.md section 8f N1 on the device: the track tables (python/motion_planning.py:139-289, 345-428) built by
+``ihm2mpc_build_tracks`` from the centre lines' spline coefficients against the host NumPy restatement (``ihm2_amd/track.py``)."""
+import numpy as np
+import pytest
+
+from conftest import make_ocp, sample_x0
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_track_tables_match_the_host_planner_on_all_tracks():
+    from ihm2_amd import track as T
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    names = T.TRACK_NAMES
+    plans = [T.track_table(n) for n in names]
+    cs = [T.fit_spline(T.load_track_geometry_data(n).center_line, curv_weight=2.0) for n in names]
+    nk = plans[0].s_ref.size
+    assert nk == 3 * T.NUMBER_SPLINE_INTERVALS
+    dummy = np.tile(np.linspace(0.0, 1.0, nk), (len(names), 1))
+    s = BatchedOcpSolver(make_ocp(), 70, dummy, np.zeros_like(dummy), track_id=np.arange(70) % len(names))
+    s.build_tracks([c[0] for c in cs], [c[1] for c in cs])
+    s_ref, kappa, X, Y, phi = s.get_tracks()
+    for t, p in enumerate(plans):
+        L = p.lap_length
+        assert np.max(np.abs(s_ref[t] - p.s_ref)) < 1e-9 * L                                    # tolerance 1e-9 of a lap
+        assert np.max(np.abs(X[t] - p.X_ref)) < 1e-9 * L and np.max(np.abs(Y[t] - p.Y_ref)) < 1e-9 * L
+        assert np.max(np.abs(kappa[t] - p.kappa_ref)) < 1e-9 * max(1.0, np.max(np.abs(p.kappa_ref)))
+        assert np.max(np.abs(np.angle(np.exp(1j * (phi[t] - p.phi_ref))))) < 1e-9
+        assert np.all(np.diff(s_ref[t]) > 0)
+    # the tables are live: a solve on them equals a solve on uploaded host tables
+    s2 = BatchedOcpSolver(make_ocp(), 70, np.stack([p.s_ref for p in plans]), np.stack([p.kappa_ref for p in plans]), track_id=np.arange(70) % len(names))
+    x0 = np.zeros((70, 8))
+    for t, p in enumerate(plans):
+        sel = np.arange(70) % len(names) == t
+        x0[sel] = sample_x0(p, int(sel.sum()), seed=100 + t)
+    for sv in (s, s2):
+        sv.set_x0(x0); sv.init_guess()
+        yref = np.zeros((70, 40, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(40)[None] / 40
+        yref_e = np.zeros((70, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+        sv.set_yref(yref); sv.set_yref_e(yref_e); sv.set_multipliers(None, None)
+    st, st2 = s.solve(), s2.solve()
+    assert np.mean(st == st2) >= 0.95           # tables agree to 1e-10: an instance at the edge of failure may fall either way
+    ok = (st == 0) & (st2 == 0)
+    assert ok.mean() > 0.8
+    assert np.max(np.abs(s.get_u()[ok] - s2.get_u()[ok]) / np.maximum(1.0, np.abs(s2.get_u()[ok]))) < 1e-6
+    # misuse
+    with pytest.raises(Exception, match="max_seg|segments"):
+        s.build_tracks([c[0][:1] for c in cs], [c[1][:1] for c in cs])
+    s.free(); s2.free()
