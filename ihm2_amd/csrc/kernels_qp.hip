@@ -57,6 +57,7 @@ struct QpArgs {
     const int32_t *track_id;
     const double *widths;
     double car_L, car_W;
+    int symmetrize;     // P_k := (P_k + P_k') / 2 in the factor sweep (riccati_mfma.hpp): needed by the open-loop unstable dynamic models
 };
 
 #define INF_BOUND 1e20
@@ -539,7 +540,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             RicLds L;
             L.gt = NS * 10; L.pv = NS * 28; L.gam = NS * 36 + N * 8; L.dz = L.gam + 2 * NS * NCK; L.kff = L.dz + NS * 10; L.Kl = L.kff + N * 4;
             L.Ginv = L.Kl + N * 16; L.hv = L.Ginv + N * 8; L.tile = L.hv + N * 8; L.hc = L.tile + 136;
-            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0);
+            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0, a.symmetrize != 0);
             if (lane < 8) dz[lane] = 0.0;
             WSYNC();
         }
@@ -981,6 +982,7 @@ static QpArgs qp_args(ihm2mpc_handle *h)
     a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
     a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
+    a.symmetrize = (h->cfg.model != IHM2MPC_MODEL_FKIN6) ? 1 : 0;
     return a;
 }
 

@@ -154,7 +154,7 @@ __device__ __forceinline__ void dyn_residual(const int N, const int lane, double
 template <int NCK, bool PATH, bool UNI, int D>
 __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, const double *__restrict__ linb, const double *__restrict__ Hs,
                                                    const double *__restrict__ CD, const RicLds L, double *__restrict__ Pg, double *__restrict__ Mg,
-                                                   const int lin_rec, const bool store_p)
+                                                   const int lin_rec, const bool store_p, const bool symmetrize)
 {
     const int g = lane >> 4, j = lane & 15;
     const int col = (j < 10) ? j : (j == 12) ? 9 : (j == 13) ? 8 : -1;
@@ -297,7 +297,7 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
                 // unstable dynamic model the antisymmetric rounding noise decided whether ill-conditioned QPs converged; the
                 // reference implementation evaluates symmetric pairs identically).  The tile's round trip is covered by the work
                 // that does not depend on it: the ring refill, the next stage's LDS operands, this stage's stores. ----
-                sm[a_tw] = S[0]; sm[a_tw + 4 * 17] = S[1];
+                if (symmetrize) { sm[a_tw] = S[0]; sm[a_tw + 4 * 17] = S[1]; }
                 {
                     const double *rec = linb + (size_t)max(k - D, 0) * lin_rec;
                     r0[d] = rec[off[0]]; r1[d] = rec[off[1]]; rB[d] = rec[offB];
@@ -322,9 +322,11 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
                 }
 #endif
                 RIC_WSYNC();
-                const double T0 = sm[a_tr], T1 = sm[a_tr + 4];
-                Pd[0] = fma(wT, T0, wS * S[0]);
-                Pd[1] = fma(wT, T1, wS * S[1]);
+                if (symmetrize) {
+                    const double T0 = sm[a_tr], T1 = sm[a_tr + 4];
+                    Pd[0] = fma(wT, T0, wS * S[0]);
+                    Pd[1] = fma(wT, T1, wS * S[1]);
+                } else { Pd[0] = S[0]; Pd[1] = S[1]; }
                 if (k > 0) prepare_compute(k - 1);
 #ifndef RIC_SKIP_A
                 if (j < 8) {

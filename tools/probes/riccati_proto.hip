@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_proto(int N, Off o, double *lin_all, con
         dyn_residual<4>(N, lane, lin, sm + o.z, sm + o.pi, sm + o.gt, sm + o.rb, REC);
         __syncthreads();
         if (r == 0) t0 = __builtin_readcyclecounter(), tr += t0 - tq;
-        riccati_sweep_mfma<NCK, PATHV != 0, UNIV != 0, RD>(N, lane, lin, Hs, CD, L, Pg + (size_t)b * (N + 1) * 64, Mg + (size_t)b * N * 64, REC, true);
+        riccati_sweep_mfma<NCK, PATHV != 0, UNIV != 0, RD>(N, lane, lin, Hs, CD, L, Pg + (size_t)b * (N + 1) * 64, Mg + (size_t)b * N * 64, REC, true, true);
         __syncthreads();
     }
     long long t1 = __builtin_readcyclecounter();
