@@ -342,8 +342,10 @@ def main():
         # KKT residuals of the QPs of the last step at the points the solver returned (inf-norms, relative to the scales the
         # interior-point tolerance 1e-6 is taken against; max over the instances of this rank) ...
         qres = solver.get_qp_residuals()
-        kkt = {"stat": float(qres[:, 0].max()), "eq": float(qres[:, 1].max()), "ineq": float(qres[:, 2].max()), "comp": float(qres[:, 3].max()),
-               "tolerance": float(ocp.solver_options.qp_tol), "relative": True}
+        okq = solver.get_status() == 0              # the residuals of a failed QP are what it stopped at, not a solution's
+        qr = qres[okq] if okq.any() else np.full((1, 4), np.nan)
+        kkt = {"stat": float(qr[:, 0].max()), "eq": float(qr[:, 1].max()), "ineq": float(qr[:, 2].max()), "comp": float(qr[:, 3].max()),
+               "tolerance": float(ocp.solver_options.qp_tol), "relative": True, "over_status_0_fraction": float(okq.mean())}
         # ... and the NLP residuals at the iterates those QPs were built at (what acados' get_stats("residuals") reports in RTI mode:
         # one SQP iteration per control step does not converge the NLP, the reference ramp moves it every step)
         res_all = solver.get_residuals()
