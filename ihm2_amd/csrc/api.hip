@@ -130,8 +130,6 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
         return fail("unknown integrator type (%d, %d)", cfg->integrator_type, cfg->sim_integrator_type);
     if (cfg->integrator_type != IHM2MPC_INTEG_ERK && cfg->M != 1)
         return fail("the IRK integrator of the shooting intervals takes one step per interval (sim_method_num_steps = 1, python/main.py:236); M = %d", cfg->M);
-    if (cfg->integrator_type != IHM2MPC_INTEG_ERK && cfg->nlp_solver_type == IHM2MPC_SQP)
-        return fail("the merit line search of the SQP mode integrates with RK4 only: use SQP_RTI with the IRK integrator");
     if (cfg->integrator_type == IHM2MPC_INTEG_ERK && rk4_unstable(cfg->dt, cfg->M))
         return fail("RK4 with %d sub-step(s) of dt = %g is unstable on the actuator lags (t_T = 1e-3 s, t_delta = 0.02 s: |z| = dt / (M t) must stay "
                     "below 2.78): use M >= %d (the reference's sim_method_num_steps = 1 belongs to its IRK integrator, python/main.py:234-236)",
@@ -199,7 +197,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
@@ -627,6 +625,19 @@ static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
         if (it == 0 && join) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         if (it == n_iter - 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));
         if (ihm2_launch_qp(h)) return fail("problem exceeds the QP kernel limits (LDS or constraint slots)");
+        if (h->cfg.integrator_type != IHM2MPC_INTEG_ERK && h->sqp_globalization) {
+            // collocation integrator: the rollouts of the line search's trial points (all step lengths of the ladder) in their own launch
+            int n_alpha = 1;
+            for (double al = h->sqp_alpha_red; al >= h->sqp_alpha_min && n_alpha < 64; al *= h->sqp_alpha_red) n_alpha++;
+            if (!h->ls_phi || h->ls_nalpha < n_alpha) {
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                if (h->ls_phi) (void)hipFree(h->ls_phi);
+                h->ls_phi = nullptr;
+                HIP_TRY(hipMalloc((void **)&h->ls_phi, (size_t)n_alpha * B * N * 8 * sizeof(double)));
+                h->ls_nalpha = n_alpha;
+            }
+            ihm2_launch_rollout_irk(h, n_alpha, h->ls_phi);
+        }
         ihm2_launch_line_search(h, it, it == n_iter - 1);
     }
     return 0;

@@ -78,6 +78,8 @@ struct ihm2mpc_handle {
     double *lam;    // (B,NS,28)
     double *slk;    // (B,NS,28) slack values of the soft sides after the last QP (0 for hard sides)
     double *res;    // (B,4)
+    double *ls_phi; // (n_alpha, B, N, 8) IRK rollouts at the trial points of the line search (SQP mode with the IRK integrator)
+    int ls_nalpha;
     double *dyn10;  // (B,35) staging of the fdyn10 plant: x (15), u (5), x_next (15); allocated on first use
     double *qp_res; // (B,4) KKT residuals of the QP at its returned point, relative to the scales of its tolerances
     int32_t *status, *qp_iter;   // (B)
@@ -126,6 +128,7 @@ void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_fail
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 // kernels_irk.hip: the collocation integrators (cfg.integrator_type / cfg.sim_integrator_type != IHM2MPC_INTEG_ERK)
 void ihm2_launch_linearize_irk(ihm2mpc_handle *h);
+void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int n_alpha, double *phi);
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,
                          const int32_t *active);
 void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last);

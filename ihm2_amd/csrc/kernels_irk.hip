@@ -340,6 +340,45 @@ __global__ __launch_bounds__(64) void k_sim_irk(int B, int model, int M, IrkTab 
         for (int a = 0; a < 8; a++) xn[(size_t)b * 8 + a] = x[a];
 }
 
+// Trial points of the SQP mode's line search (sqp_body.hpp): Phi(xp_k + al (x_k - xp_k), up_k + al (u_k - up_k)) for EVERY step length of
+// the backtracking ladder al_j = rho^j >= alpha_min and every interval, one quad each -> phi (n_alpha, B, N, 8).  The line search kernel
+// has one lane per stage; the collocation step wants four, so its rollouts are done here, all trial points at once (an instance
+// rarely needs more than the first: the rest is cheap insurance against a second launch per backtrack).
+template <int MODEL>
+__global__ __launch_bounds__(64) void k_rollout_irk(int B, int N, int M, int n_alpha, double alpha_red, IrkTab tab, int nknots, const double *__restrict__ s_ref,
+                                                    const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *__restrict__ x,
+                                                    const double *__restrict__ u, const double *__restrict__ xp, const double *__restrict__ up, double *phi)
+{
+    const long total = (long)n_alpha * B * N;
+    const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 2);
+    const long pr = min(q, total - 1);
+    const int st = threadIdx.x & 3;
+    const int j = (int)(pr / ((long)B * N));
+    const long rem = pr - (long)j * B * N;
+    const int b = (int)(rem / N), k = (int)(rem % N);
+    double al = 1.0;
+    for (int jj = 0; jj < j; jj++) al *= alpha_red;          // the very products the line search forms
+    const size_t ex = ((size_t)b * (N + 1) + k) * 8, eu = ((size_t)b * N + k) * 2;
+    double xs[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) xs[i] = xp[ex + i] + al * (x[ex + i] - xp[ex + i]);
+    const double u_T = up[eu] + al * (u[eu] - up[eu]), u_d = up[eu + 1] + al * (u[eu + 1] - up[eu + 1]);
+    const int tid = track_id[b];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, xs[0]);
+    IRK_ROWS(rows, tab, st)
+    const double hb = rows.hb;
+    for (int m = 0; m < M; m++) {
+        double K[8], J[8][10];
+        irk_step<MODEL, false>(st, rows, xs, u_T, u_d, trk, K, J);
+#pragma unroll
+        for (int i = 0; i < 8; i++) xs[i] += quad_sum(hb * K[i]);
+    }
+    if (q < total && st == 0)
+#pragma unroll
+        for (int i = 0; i < 8; i++) phi[(size_t)pr * 8 + i] = xs[i];
+}
+
 // host: tableau + the constant actuator blocks (I + h/t A)^-1 for the step size h
 static void invert4(const double (&Min)[4][4], double (&inv)[4][4])
 {
@@ -394,6 +433,19 @@ void ihm2_launch_linearize_irk(ihm2mpc_handle *h)
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6) LAUNCH_IRK(IHM2MPC_MODEL_FDYN6);
     else LAUNCH_IRK(IHM2MPC_MODEL_FKIN6);
 #undef LAUNCH_IRK
+}
+
+void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int n_alpha, double *phi)
+{
+    const long total = (long)n_alpha * h->B * h->N;
+    const int blocks = (int)((total + 15) / 16);
+    const IrkTab tab = make_tab(h->cfg.integrator_type, h->cfg.dt / h->cfg.M);
+#define LAUNCH_RO(MD) hipLaunchKernelGGL(k_rollout_irk<MD>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, n_alpha, h->sqp_alpha_red, tab, h->cfg.nknots, \
+                                         h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->ls_x, h->ls_u, phi)
+    if (h->cfg.model == IHM2MPC_MODEL_FDYN6U) LAUNCH_RO(IHM2MPC_MODEL_FDYN6U);
+    else if (h->cfg.model == IHM2MPC_MODEL_FDYN6) LAUNCH_RO(IHM2MPC_MODEL_FDYN6);
+    else LAUNCH_RO(IHM2MPC_MODEL_FKIN6);
+#undef LAUNCH_RO
 }
 
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)

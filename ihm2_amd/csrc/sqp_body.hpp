@@ -25,6 +25,8 @@ struct LsArgs {
     const double *res;
     int32_t *status, *qp_iter, *done, *sqp_status, *sqp_iter, *qp_acc;
     double *alpha, *u0;
+    const double *phi;               // IRK: Phi at the trial points, (n_alpha, B, N, 8), from k_rollout_irk; nullptr: RK4 rollouts in this kernel
+    int n_alpha;
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -143,7 +145,7 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
     // merit at xp + al (x - xp): cost (with the slack penalties) and weighted infeasibility, summed over the wave;
     // at_lin: al = 0, the dynamics defects are the b_k of the linearisation records (no rollout)
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
-    auto merit = [&](double al, bool at_lin, double &cost_out, double &inf_out) {
+    auto merit = [&](double al, int jtrial, bool at_lin, double &cost_out, double &inf_out) {
         double cost = 0.0, inf = 0.0;
         for (int k = lane; k < NS; k += 64) {
             double xk[8], cv[14];
@@ -172,11 +174,17 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
                     for (int i = 0; i < 8; i++) inf += wpib[(k + 1) * 8 + i] * fabs(linb[(size_t)k * LIN_REC + 80 + i]);
                 } else {
                     double xn[8];
+                    if (a.phi) {            // collocation integrator: the rollout of this trial point was done by k_rollout_irk
+                        const double *ph = a.phi + (((size_t)jtrial * a.B + b) * N + k) * 8;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) xn[i] = xk[i];
-                    TrackSeg trk;
-                    trk.init(sr, kr, a.nknots, xn[0]);
-                    rollout<MODEL>(xn, uT, ud, trk, a.M, hstep);
+                        for (int i = 0; i < 8; i++) xn[i] = ph[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) xn[i] = xk[i];
+                        TrackSeg trk;
+                        trk.init(sr, kr, a.nknots, xn[0]);
+                        rollout<MODEL>(xn, uT, ud, trk, a.M, hstep);
+                    }
                     for (int i = 0; i < 8; i++) {
                         const int e1 = (k + 1) * 8 + i;
                         inf += wpib[e1] * fabs(xn[i] - (xpb[e1] + al * (xb[e1] - xpb[e1])));
@@ -238,7 +246,7 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
     };
 
     double c0, i0;
-    merit(0.0, true, c0, i0);
+    merit(0.0, 0, true, c0, i0);
     const double m0 = c0 + i0;
     double D = 0.0;
     if (a.use_suff) {       // grad cost . step - infeasibility at alpha = 0 (the linearised constraints hold at the full step)
@@ -254,9 +262,9 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
         D = fmin(wave_sum(acc) - i0, 0.0);
     }
     double al = 1.0;
-    for (;;) {              // at most log(alpha_min) / log(alpha_red) + 1 trials: al shrinks every pass
+    for (int jtrial = 0;; jtrial++) {              // at most log(alpha_min) / log(alpha_red) + 1 trials: al shrinks every pass
         double c1, i1;
-        merit(al, false, c1, i1);
+        merit(al, jtrial, false, c1, i1);
         const double m1 = c1 + i1;
         if (a.use_suff ? (m1 - m0 <= a.eps * al * D) : (m1 < m0)) break;
         al *= a.alpha_red;
@@ -298,6 +306,7 @@ static inline LsArgs make_ls_args(ihm2mpc_handle *h)
     a.res = h->res; a.status = h->status; a.qp_iter = h->qp_iter;
     a.done = h->ls_done; a.sqp_status = h->ls_status; a.sqp_iter = h->ls_iter; a.qp_acc = h->ls_qp_acc;
     a.alpha = h->ls_alpha; a.u0 = h->u0;
+    a.phi = (h->cfg.integrator_type != IHM2MPC_INTEG_ERK) ? h->ls_phi : nullptr; a.n_alpha = h->ls_nalpha;
     return a;
 }
 

@@ -74,7 +74,9 @@ extern "C" {
 /* integrators (AcadosOcpOptions.integrator_type / collocation_type, AcadosSimOpts): ERK = classical RK4 x M sub-steps; IRK = 4-stage
  * collocation x M steps, 3 Newton iterations per step from K = 0 with a fresh Jacobian each (acados' defaults), forward
  * sensitivities by the implicit-function theorem; GL4 = GAUSS_LEGENDRE (acados' default, python/main.py:234-236), RADAU4 =
- * GAUSS_RADAU_IIA (python/main.py:395-400, python/sim.py:28-33) */
+ * GAUSS_RADAU_IIA (python/main.py:395-400, python/sim.py:28-33).  Both NLP solver types run on either integrator (the live options of
+ * python/main.py:227-238 are SQP + MERIT_BACKTRACKING + IRK); the persistent loop (ihm2mpc_run_steps in one launch) is RK4 only and
+ * falls back to launches per step otherwise. */
 #define IHM2MPC_INTEG_ERK 0
 #define IHM2MPC_INTEG_IRK_GL4 1
 #define IHM2MPC_INTEG_IRK_RADAU4 2

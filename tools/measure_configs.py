@@ -136,6 +136,9 @@ if __name__ == "__main__":
                    (rti_throughput, dict(model="fkin6", B=1024, integrator="IRK")),
                    (rti_throughput, dict(model="fkin6", B=8192, integrator="IRK")),
                    (rti_throughput, dict(model="fdyn6u", B=8192, terminal_bounds="stage", track_rows="soft", recover=True, integrator="IRK")),
+                   # the live options as a whole (python/main.py:227-238): SQP x 2, MERIT_BACKTRACKING, IRK
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", integrator="IRK")),
+                   (rti_throughput, dict(model="fkin6", B=8192, sqp="MERIT_BACKTRACKING", integrator="IRK")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0))),
                    (closed_loop_config5, dict(B=4096, steps=200, device_loop=True)),
