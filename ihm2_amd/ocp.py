@@ -212,8 +212,8 @@ class AcadosOcpOptions:
     # implementation knobs
     qp_solver_iter_max: int = 30
     qp_tol: float = 1e-6                          # relative (see csrc: scaled by |g|_inf and |b|_inf); ~sqrt(eps) is the fp64 limit
-    qp_mu0: float = 0.03               # initial barrier parameter = qp_mu0 * max(1, |g|_inf)
-    qp_tau0: float = 0.3               # lower clamp of the initial slacks (1/4 of the width for narrow two-sided constraints)
+    qp_mu0: float = 0.1                # initial barrier parameter = qp_mu0 * max(1, |g|_inf)
+    qp_tau0: float = 1.0               # lower clamp of the initial slacks (1/4 of the width for narrow two-sided constraints)
     cost_scale_stage: float | None = None         # None -> time step (acados scales stage cost by dt)
     nlp_tol: float = 1e-6                         # SQP mode: stop when all four KKT residuals <= tol
 

