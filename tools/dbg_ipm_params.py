@@ -1,6 +1,8 @@
 """Sweep of the interior-point start parameters (qp_mu0, qp_tau0) on the bench workload: mean IPM iterations, statuses, step time."""
 import sys, time, itertools
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import make_ocp, sample_x0
 from ihm2_amd.solver import BatchedOcpSolver

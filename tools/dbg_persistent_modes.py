@@ -1,5 +1,9 @@
+"""Diagnostic: the persistent loop (500 steps, B = 1024) in its four modes -- RTI, SQP FIXED_STEP, SQP MERIT_BACKTRACKING, RTI with soft
+track rows -- solves/s and ms per step (a quick regression check of the register-starved k_steps instantiations after a kernel change)."""
 import sys, json
-sys.path.insert(0, "/root/repo/tools"); sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, ROOT)
 from measure_configs import rti_throughput
 for kw in (dict(model="fkin6", B=1024, persistent=True, steps=500, warmup=20),
            dict(model="fkin6", B=1024, sqp="FIXED_STEP", persistent=True, steps=500, warmup=20),

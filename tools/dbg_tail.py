@@ -1,5 +1,8 @@
+"""Diagnostic: IPM iterations per instance over a 20-step persistent launch (the launch ends with its slowest instance: DESIGN.md section 7 (f))."""
 import sys, os, numpy as np
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import make_ocp, sample_x0
 from ihm2_amd.solver import BatchedOcpSolver
 from ihm2_amd.track import track_table
