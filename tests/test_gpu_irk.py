@@ -95,11 +95,13 @@ def test_irk_plant_step_matches_oracle(track, plant):
 
 def test_irk_needs_a_fraction_of_the_rk4_work(track):
     """Linearisation time at B = 1024: IRK (3 Newton iterations x 4 stages + 4 = 16 model evaluations per interval) beside RK4 x 25
-    (100 evaluations); printed for DESIGN.md, asserted only to be faster."""
+    (100 evaluations); printed for DESIGN.md.  Asserted on the dynamic model, where the gap is 4x (1.5 against 6.1 ms at B = 8192): the
+    kinematic model's 0.135 against 0.19 ms is too close for a timing assertion on a shared box."""
     from ihm2_amd.solver import BatchedOcpSolver
 
     B, t = 1024, {}
-    for name, kw in (("RK4x25", dict(M=25)), ("IRK GL4x1", dict(M=1, integrator_type="IRK"))):
+    for name, kw in (("RK4x25", dict(M=25)), ("IRK GL4x1", dict(M=1, integrator_type="IRK")),
+                     ("fdyn6u RK4x25", dict(M=25, model="fdyn6u")), ("fdyn6u IRK GL4x1", dict(M=1, integrator_type="IRK", model="fdyn6u"))):
         s = BatchedOcpSolver(make_ocp(**kw), B, track.s_ref, track.kappa_ref)
         s.set_x0(sample_x0(track, B)); s.init_guess()
         s.linearize(); s.synchronize()
@@ -110,7 +112,7 @@ def test_irk_needs_a_fraction_of_the_rk4_work(track):
         t[name] = (time.perf_counter() - t0) / 20 * 1e3
         s.free()
     print("linearisation of 1024 x 40 intervals [ms]:", t)
-    assert t["IRK GL4x1"] < t["RK4x25"]
+    assert t["fdyn6u IRK GL4x1"] < 0.7 * t["fdyn6u RK4x25"]
 
 
 def test_sim_solver_object_replays_the_reference_plant_calls(track):
