@@ -57,7 +57,7 @@ struct QpArgs {
     const int32_t *track_id;
     const double *widths;
     double car_L, car_W;
-    int symmetrize;     // P_k := (P_k + P_k') / 2 in the factor sweep (riccati_mfma.hpp): needed by the open-loop unstable dynamic models
+    int symmetrize;     // P_k := (P_k + P_k') / 2 in the factor sweep (riccati_mfma.hpp): needed by the open-loop unstable dynamic model as written (fdyn6)
 };
 
 #define INF_BOUND 1e20
@@ -982,7 +982,7 @@ static QpArgs qp_args(ihm2mpc_handle *h)
     a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
     a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
-    a.symmetrize = (h->cfg.model != IHM2MPC_MODEL_FKIN6) ? 1 : 0;
+    a.symmetrize = (h->cfg.model == IHM2MPC_MODEL_FDYN6) ? 1 : 0;
     return a;
 }
 
