@@ -12,4 +12,5 @@ import measure_configs as m  # noqa: E402
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    print(json.dumps(m.rti_throughput(model="fkin6", B=B, sqp="MERIT_BACKTRACKING", steps=40)))
+    integ = sys.argv[2] if len(sys.argv) > 2 else "ERK"          # "IRK": the live options as a whole (python/main.py:227-238)
+    print(json.dumps(m.rti_throughput(model="fkin6", B=B, sqp="MERIT_BACKTRACKING", steps=40, integrator=integ)))
