@@ -153,6 +153,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     h->N = cfg->N;
     h->NS = cfg->N + 1;
     h->n_cu = prop.multiProcessorCount;
+    { const char *e = getenv("IHM2MPC_BLOCK_QP"); h->block_qp = !(e && e[0] == '0'); }
     const size_t B = h->B, N = h->N, NS = h->NS;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -164,6 +165,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(track_id, B);
     DA(Hs, NS * 100); DA(Gy, NS * 120); DA(lbx, NS * 8); DA(ubx, NS * 8); DA(lbu, N * 2); DA(ubu, N * 2);
     DA(CD, N * 20); DA(lg, N * 2); DA(ug, N * 2);
+    DA(slot_kc_blk, 1024); DA(slot_lb_blk, 1024); DA(slot_ub_blk, 1024);
     DA(slot_kc, MAX_SLOTS); DA(slot_lb, MAX_SLOTS); DA(slot_ub, MAX_SLOTS); DA(slot_zw, MAX_SLOTS); DA(slot_Zw, MAX_SLOTS);
     DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2);
     DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
@@ -197,7 +199,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
@@ -399,6 +401,26 @@ static int rebuild_slots(ihm2mpc_handle *h)
             kc[e] = s.kc; slb[e] = s.lb; sub[e] = s.ub; zw[e] = s.zw; Zw[e] = s.Zw;
         }
     h->nslots = total; h->m_act = m_act; h->nslot_lane = per_lane; h->nsoft_lane = soft_lane;
+    // the same rows over 256 lanes for the four-wave latency kernel (all-hard tables: a row is one two-sided slot)
+    h->nslot_lane_blk = 0;
+    if (soft_lane == 0 && total > 0 && total <= 1024) {
+        const int per_blk = (total + 255) / 256;
+        std::vector<int32_t> kcb((size_t)per_blk * 256, -1);
+        std::vector<double> lbb((size_t)per_blk * 256, -INFINITY), ubb((size_t)per_blk * 256, INFINITY);
+        int cnt = 0;
+        for (int k = 0; k < NS; k++)
+            for (int c = 0; c < NC; c++) {
+                const double lb = h->host_lb[k * NC + c], ub = h->host_ub[k * NC + c];
+                if (!std::isfinite(lb) && !std::isfinite(ub)) continue;
+                const size_t e = (size_t)(cnt % 256) + 256 * (size_t)(cnt / 256);
+                kcb[e] = k * 16 + c; lbb[e] = lb; ubb[e] = ub;
+                cnt++;
+            }
+        HIP_TRY(hipMemcpyAsync(h->slot_kc_blk, kcb.data(), kcb.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (upload_shared(h, lbb.data(), h->slot_lb_blk, lbb.size()) || upload_shared(h, ubb.data(), h->slot_ub_blk, ubb.size())) return -1;
+        h->nslot_lane_blk = per_blk;
+    }
     if (upload_shared(h, h->host_lb, h->st_lb, (size_t)NS * NC) || upload_shared(h, h->host_ub, h->st_ub, (size_t)NS * NC) ||
         upload_shared(h, h->host_sz, h->st_sz, (size_t)NS * NLAM) || upload_shared(h, h->host_sZ, h->st_sZ, (size_t)NS * NLAM))
         return -1;

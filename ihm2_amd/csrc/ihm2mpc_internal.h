@@ -53,6 +53,10 @@ struct ihm2mpc_handle {
     int nslots, m_act;             // m_act: number of one-sided inequality pairs (finite sides + one per soft slack)
     int nslot_lane, nsoft_lane;    // slots per lane / soft slots per lane (maxima over the 64 lanes)
     int32_t *slot_kc;              // (nslot_lane*64) stage * 16 + row, -1 = padding
+    int32_t *slot_kc_blk;          // the same rows spread over 256 lanes (k_qp_block: four wavefronts per instance), all-hard tables only
+    double *slot_lb_blk, *slot_ub_blk;
+    int nslot_lane_blk;            // 0: no such table (soft sides present)
+    bool block_qp;                 // use k_qp_block for batches of at most one instance per CU (IHM2MPC_BLOCK_QP=0 turns it off)
     double *slot_lb, *slot_ub;     // raw bounds, +-inf if that side is absent (soft slots are one-sided)
     double *slot_zw, *slot_Zw;     // slack cost zw s + 1/2 Zw s^2 of a soft slot; Zw < 0 = hard slot
     // host copies the table is rebuilt from (set_bounds / set_soft may come in either order)

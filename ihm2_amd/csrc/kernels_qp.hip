@@ -163,10 +163,16 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
 
 // The QP of instance b, solved by the calling wavefront (all 64 lanes, lane = threadIdx.x); sm: the block's dynamic LDS.
 // Called by k_qp_wave (one launch per RTI iteration) and by the persistent per-instance loop k_steps.
-template <int NSLOT, int NSOFT, int PATH, int UNI>
+// NW > 1 (k_qp_block, the latency kernel for batches smaller than the chip): NW wavefronts share the instance.  The phases that
+// are parallel over stages / rows run over all NT = 64 NW threads, the constraint slots are spread over NT lanes (NSLOT is then the
+// count per lane of THAT table), reductions go wave -> LDS -> block, hand-offs are s_barriers; the three sequential sweeps run on
+// wave 0 while the others wait.  NW == 1 compiles to exactly the single-wave code (tid == lane, BSYNC == WSYNC).
+template <int NSLOT, int NSOFT, int PATH, int UNI, int NW = 1>
 __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, double *sm)
 {
-    const int lane = threadIdx.x;
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#define BSYNC() do { if (NW == 1) WSYNC(); else __syncthreads(); } while (0)
     const int N = a.N, NS = N + 1;
     // constraint rows per stage held in LDS: 8 x boxes, 2 u boxes, 2 general rows (+ 2 track rows); the multiplier arrays in
     // HBM always have the full NLAM = 28 columns (14 lower sides, then 14 upper sides)
@@ -197,6 +203,25 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #define HS(k, i, l) (HL ? Hl[(((k) == N) ? 100 : 0) + (i) * 10 + (l)] : a.Hs[((k) * 10 + (i)) * 10 + (l)])
 #define CDV(k, r, j) (CL ? CDl[(r) * 10 + (j)] : a.CD[((k) * 2 + (r)) * 10 + (j)])
 
+    // reductions over the instance's threads: wave butterfly, then (NW > 1) one LDS word per wave -- the transpose tile of the factor
+    // sweep is free outside the sweep
+    auto blk_reduce = [&](double v, auto op) -> double {
+        v = wave_reduce(v, op);
+        if (NW > 1) {
+            __syncthreads();                    // earlier readers of the words are done
+            if (lane == 0) tile[wv] = v;
+            __syncthreads();
+            v = tile[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) v = op(v, tile[w]);
+        }
+        return v;
+    };
+    auto blk_max = [&](double v) { return blk_reduce(v, [](double x, double y) { return fmax(x, y); }); };
+    auto blk_min = [&](double v) { return blk_reduce(v, [](double x, double y) { return fmin(x, y); }); };
+    auto blk_sum = [&](double v) { return blk_reduce(v, [](double x, double y) { return x + y; }); };
+    auto blk_nanmax = [&](double v) { return blk_reduce(v, [](double x, double y) { return nanmax(x, y); }); };
+
     const double *xb = a.x + (size_t)b * NS * 8;
     const double *ub = a.u + (size_t)b * N * 2;
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
@@ -209,25 +234,26 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
-    if (HL) for (int e = lane; e < 200; e += 64) Hl[e] = a.Hs[(e < 100) ? e : N * 100 + (e - 100)];
-    if (CL && lane < 20) CDl[lane] = a.CD[lane];
-    if (UNI) WSYNC();
+    if (HL) for (int e = tid; e < 200; e += NT) Hl[e] = a.Hs[(e < 100) ? e : N * 100 + (e - 100)];
+    if (CL && tid < 20) CDl[tid] = a.CD[tid];
+    if (UNI) BSYNC();
     // Rows of the batch-shared Hessians with at most three non-zeros each (the reference's cost y = [x; u; x_act - u], python/mpc.py:49-58,
     // couples an actuator state with its own input only): phase (i) of every iteration then multiplies the non-zeros alone, in column
     // order -- the same sums as the dense loop, whose other terms are exact zeros.
     bool h_sparse = false;
     if (HL) {
         int cnt = 0;
-        if (lane < 20) {
+        if (tid < 20) {
 #pragma unroll
             for (int l = 0; l < 10; l++) {
-                const double v = Hl[lane * 10 + l];
-                if (v != 0.0) { if (cnt < 3) { spv[lane * 3 + cnt] = v; spc[lane * 3 + cnt] = l; } cnt++; }
+                const double v = Hl[tid * 10 + l];
+                if (v != 0.0) { if (cnt < 3) { spv[tid * 3 + cnt] = v; spc[tid * 3 + cnt] = l; } cnt++; }
             }
-            for (int q = cnt; q < 3; q++) { spv[lane * 3 + q] = 0.0; spc[lane * 3 + q] = 0; }
+            for (int q = cnt; q < 3; q++) { spv[tid * 3 + q] = 0.0; spc[tid * 3 + q] = 0; }
         }
-        h_sparse = __ballot(cnt > 3) == 0ull;
-        WSYNC();
+        h_sparse = __ballot(cnt > 3) == 0ull;           // the 20 rows sit in wave 0
+        if (NW > 1) h_sparse = blk_max((wv == 0 && !h_sparse) ? 1.0 : 0.0) == 0.0;
+        BSYNC();
     }
     double sg = 1.0, sb = 1.0, r_stat = 0.0, r_eq = 0.0;
     double w_R = 0.0, w_L = 0.0;
@@ -235,17 +261,17 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         // track rows (old/generate_acaods_interface.py:191-212) at the iterate, stages 1..N:
         //   h_R = n - L/2 sin|psi| + W/2 cos(psi) - w_R ,  h_L = -n + L/2 sin|psi| + W/2 cos(psi) - w_L
         // gradients (1, a_R) and (-1, a_L) in (n, psi); d|psi| = sign(psi), sign(0) = 0
-        const int tid = a.track_id[b];
-        w_R = a.widths[tid * 2 + 0]; w_L = a.widths[tid * 2 + 1];
-        for (int k = lane; k < NS; k += 64) {
+        const int trk = a.track_id[b];
+        w_R = a.widths[trk * 2 + 0]; w_L = a.widths[trk * 2 + 1];
+        for (int k = tid; k < NS; k += NT) {
             const double psi = xb[k * 8 + 2], sgn = (psi > 0.0) - (psi < 0.0);
             const double dfoot = -0.5 * a.car_L * cos(fabs(psi)) * sgn, dlat = -0.5 * a.car_W * sin(psi);
             hc[k * 2 + 0] = (k >= 1) ? dfoot + dlat : 0.0;
             hc[k * 2 + 1] = (k >= 1) ? -dfoot + dlat : 0.0;
         }
-        WSYNC();
+        BSYNC();
     }
-    for (int e = lane; e < NS * 10; e += 64) {
+    for (int e = tid; e < NS * 10; e += NT) {
         const int k = e / 10, j = e % 10;
         double acc = 0.0;
 #pragma unroll
@@ -283,17 +309,17 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         }
         if (counted) r_stat = fmax(r_stat, fabs(st));
     }
-    for (int e = lane; e < N * 8; e += 64) {
+    for (int e = tid; e < N * 8; e += NT) {
         const double bl = linb[(size_t)(e / 8) * LIN_REC + 80 + (e % 8)];
         sb = fmax(sb, fabs(bl));
         r_eq = fmax(r_eq, fabs(bl));
     }
-    if (lane < 8) {
-        const double d = a.x0[(size_t)b * 8 + lane] - xb[lane];
+    if (tid < 8) {
+        const double d = a.x0[(size_t)b * 8 + tid] - xb[tid];
         sb = fmax(sb, fabs(d));
         r_eq = fmax(r_eq, fabs(d));
     }
-    sg = wave_max(sg); sb = wave_max(sb);
+    sg = blk_max(sg); sb = blk_max(sb);
 
     // constraint slots owned by this lane
     int s_kc[NSLOT];
@@ -311,7 +337,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double r_ineq = 0.0, r_comp = 0.0;
 #pragma unroll
     for (int r = 0; r < NSLOT; r++) {
-        const int s = lane + 64 * r;
+        const int s = tid + NT * r;
         s_kc[r] = -1; s_dl[r] = -INFINITY; s_du[r] = INFINITY;
         lam_l[r] = lam_u[r] = 0.0; t_l[r] = t_u[r] = 1.0;
         const int kc = (s < a.nslots) ? a.slot_kc[s] : -1;
@@ -340,8 +366,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (fin(ubd)) { s_du[r] = ubd - cz; if (!soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + 14 + c] * s_du[r])); } }
         }
     }
-    r_stat = wave_max(r_stat); r_eq = wave_max(r_eq); r_ineq = wave_max(r_ineq); r_comp = wave_max(r_comp);
-    if (lane == 0) {
+    r_stat = blk_max(r_stat); r_eq = blk_max(r_eq); r_ineq = blk_max(r_ineq); r_comp = blk_max(r_comp);
+    if (tid == 0) {
         double *rs = a.res + (size_t)b * 4;
         rs[0] = r_stat; rs[1] = r_eq; rs[2] = r_ineq; rs[3] = r_comp;
     }
@@ -364,9 +390,9 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 
 /*@S:0*/
     // ------------------------------------------------------------------ initial point
-    for (int e = lane; e < NS * 10; e += 64) z[e] = (e < 8) ? a.x0[(size_t)b * 8 + e] - xb[e] : 0.0;
-    for (int e = lane; e < NS * 8; e += 64) pi[e] = 0.0;
-    WSYNC();
+    for (int e = tid; e < NS * 10; e += NT) z[e] = (e < 8) ? a.x0[(size_t)b * 8 + e] - xb[e] : 0.0;
+    for (int e = tid; e < NS * 8; e += NT) pi[e] = 0.0;
+    BSYNC();
 #pragma unroll
     for (int r = 0; r < NSLOT; r++) {
         if (s_kc[r] < 0) continue;
@@ -394,8 +420,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     for (it = 0;; it++) {
 /*@S:1*/
         // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
-        for (int e = lane; e < NS * NCK; e += 64) cf[e] = 0.0;
-        WSYNC();
+        for (int e = tid; e < NS * NCK; e += NT) cf[e] = 0.0;
+        BSYNC();
         double mu_acc = 0.0, res_gs = 0.0;
         res_d = 0.0; res_m = 0.0;
 #pragma unroll
@@ -417,12 +443,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));     // the two halves of a split slot share a lane
         }
 /*@S:14*/
-        WSYNC();
+        BSYNC();
         // ---- stationarity and dynamics residuals ----
         // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
         // (an unrolled variant that forms all values before the first store -- QP gradient entries and LDS operands of all passes in
         // flight together -- was 30 % faster here but cost the slot phases twice that in spilled slot registers)
-        for (int e = lane; e < NS * 10; e += 64) {
+        for (int e = tid; e < NS * 10; e += NT) {
             const int k = e / 10, j = e % 10;
             double acc = gb[e];
             if (HL && h_sparse) {
@@ -448,26 +474,26 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #define NORMS_AND_CHECK() \
  \
         res_g = 0.0; res_b = 0.0; \
-        for (int e = lane; e < NS * 10; e += 64) { \
+        for (int e = tid; e < NS * 10; e += NT) { \
             const int k = e / 10, j = e % 10; \
             double v = gt[e]; \
             if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; } \
             res_g = nanmax(res_g, fabs(v)); \
         } \
-        for (int e = lane; e < N * 8; e += 64) res_b = nanmax(res_b, fabs(rb[e])); \
+        for (int e = tid; e < N * 8; e += NT) res_b = nanmax(res_b, fabs(rb[e])); \
         res_g = nanmax(res_g, res_gs); \
-        res_g = wave_nanmax(res_g); res_b = wave_nanmax(res_b); res_d = wave_nanmax(res_d); res_m = wave_nanmax(res_m); \
-        mu = wave_sum(mu_acc) * inv_m; \
+        res_g = blk_nanmax(res_g); res_b = blk_nanmax(res_b); res_d = blk_nanmax(res_d); res_m = blk_nanmax(res_m); \
+        mu = blk_sum(mu_acc) * inv_m; \
         if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; } \
         if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; } \
         if (it >= a.iter_max) { qstatus = 1; break; } \
-        WSYNC();
-        WSYNC();
+        BSYNC();
+        BSYNC();
 /*@S:2*/
         // (ii) [A B]' pi_{k+1} and the dynamics residual rb_k = A z_k + B u_k + b_k - z_{k+1} (LDS and slot 88 of the record, where
         // the factor sweep picks it up): one dot product per lane, all stages in parallel
-        dyn_residual<4>(N, lane, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
-        WSYNC();
+        dyn_residual<4, NT>(N, tid, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
+        BSYNC();
 /*@S:3*/
         NORMS_AND_CHECK()
         // separate step lengths for the primal (z, t, s) and the dual (pi, lam, lam_s) variables, as HPIPM's split_step
@@ -476,8 +502,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         // ---- barrier weights and gradient coefficients of the owned slots -> LDS (pass 0: predictor; pass 1: corrector) ----
         auto slot_coeffs = [&](int pass) {
             // ---- barrier weights and gradient coefficients of the owned slots -> LDS ----
-            for (int e = lane; e < NS * NCK; e += 64) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
-            WSYNC();
+            for (int e = tid; e < NS * NCK; e += NT) { cf[e] = 0.0; if (pass == 0) gam[e] = 0.0; }
+            BSYNC();
             const double mu_t = fmax(sigma * mu, mu_floor);
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
@@ -508,11 +534,11 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 }
                 SLOT_ACC(cf[s_kc[r]], c);
             }
-            WSYNC();
+            BSYNC();
         };
         // modified gradient: gt += R' cf (pass 1 adds its increment on top of the predictor's gradient)
         auto add_coeffs = [&]() {
-            for (int e = lane; e < NS * 10; e += 64) {
+            for (int e = tid; e < NS * 10; e += NT) {
                 const int k = e / 10, j = e % 10;
                 double acc = gt[e] + cf[k * NCK + j];
                 if (k < N) {
@@ -525,7 +551,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 }
                 gt[e] = acc;        // pass 1 adds its increment on top of the predictor's gradient
             }
-            WSYNC();
+            BSYNC();
 
         };
         slot_coeffs(0);
@@ -534,7 +560,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         // ---- factorisation and the predictor's vector recursion: P_k, M_k -> HBM/L2; K_k, Guu^-1, p_k, kff_k, c_k = rb_k - B kff_k
         // and P_{k+1} rb_k -> LDS (riccati_mfma.hpp).  The records' rb slots were written by this wave: wait for them. ----
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
-        {
+        if (wv == 0) {
             // offsets of the carve-up above as plain integers (a difference of two generic pointers into LDS makes the compiler
             // build both flat addresses -- and mis-fold their null checks in the register-starved instantiations)
             RicLds L;
@@ -542,8 +568,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             L.Ginv = L.Kl + N * 16; L.hv = L.Ginv + N * 8; L.tile = L.hv + N * 8; L.hc = L.tile + 136;
             riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0, a.symmetrize != 0);
             if (lane < 8) dz[lane] = 0.0;
-            WSYNC();
         }
+        BSYNC();
 #undef NORMS_AND_CHECK
         for (int pass = 0; pass < 2; pass++) {
             const double mu_t = fmax(sigma * mu, mu_floor);
@@ -554,19 +580,19 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             // ---- corrector's vector recursion: p_k = gt_x - K'gt_u + M_k'(P_{k+1} rb_k + p_{k+1}) (the predictor's came out of
             // the factor sweep) ----
             // the part without p_{k+1} for all stages in parallel ...
-            for (int e = lane; e < NS * 8; e += 64) {
+            for (int e = tid; e < NS * 8; e += NT) {
                 const int k = e >> 3, j = e & 7;
                 double v = gt[k * 10 + j];
                 if (k < N) v -= Kl[k * 16 + j] * gt[k * 10 + 8] + Kl[k * 16 + 8 + j] * gt[k * 10 + 9];
                 pv[e] = v;
             }
-            WSYNC();
+            BSYNC();
 /*@S:7*/
             // ... then the recursion itself, entirely in registers.  A lane is (g, w) = (lane >> 3, lane & 7).  The contraction runs
             // over w inside the group on even steps (result: one value per group g) and over g across the groups on odd steps
             // (result: one value per position w), so the output of a step is already laid out as the input of the next:
             //   even: lane holds M[w][g], q_w = Prb_k[w] + p_{k+1}[w] -> p_k[g] ;  odd: lane holds M[g][w], q_g -> p_k[w]
-            {
+            if (wv == 0) {
                 const int g = lane >> 3, w = lane & 7;
                 double pw = pv[N * 8 + w], pg = 0.0;
                 stream_rows<-1, 8, 4>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
@@ -580,12 +606,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                             if (g == 0) pv[k * 8 + w] = pw;
                         }
                     });
-                WSYNC();
             }
+            BSYNC();
 /*@S:8*/
             // feed-forward terms kff_k = Guu^-1 (gt_u + B'(P_{k+1} rb_k + p_{k+1})) and the affine part
             // c_k = rb_k - B kff_k of the forward recursion, all stages in parallel
-            for (int k = lane; k < N; k += 64) {
+            for (int k = tid; k < N; k += NT) {
                 const double *rec = linb + (size_t)k * LIN_REC;
                 double g0 = gt[k * 10 + 8], g1 = gt[k * 10 + 9];
                 double Bk[16];
@@ -604,14 +630,14 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #pragma unroll
                 for (int i = 0; i < 8; i++) dz[(k + 1) * 10 + i] = rb[k * 8 + i] - Bk[i * 2] * kf0 - Bk[i * 2 + 1] * kf1;
             }
-            if (lane < 8) dz[lane] = 0.0;
-            WSYNC();
+            if (tid < 8) dz[tid] = 0.0;
+            BSYNC();
             }
 
 /*@S:9*/
             // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k, same alternating register layout ----
             //   even: lane holds M[g][w], dx_k[w] -> dx_{k+1}[g] ;  odd: lane holds M[w][g], dx_k[g] -> dx_{k+1}[w]
-            {
+            if (wv == 0) {
                 const int g = lane >> 3, w = lane & 7;
                 double dxw = dz[w], dxg = 0.0;
                 stream_rows<+1, 8, 4>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
@@ -625,12 +651,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                             if (g == 0) dz[(k + 1) * 10 + w] = dxw;
                         }
                     });
-                WSYNC();
             }
+            BSYNC();
 /*@S:10*/
             // inputs and costate steps of all stages in parallel
             const bool want_dpi = (pass == 1) || (a.m_act == 0);
-            for (int e = lane; e < NS * 2; e += 64) {
+            for (int e = tid; e < NS * 2; e += NT) {
                 const int k = e >> 1, aa = e & 1;
                 double acc = 0.0;
                 if (k < N) {
@@ -645,17 +671,17 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 // dpi_k = P_k dx_k + p_k.  P_k is symmetric: column i of its RIC_IDX layout holds the pairs (P[l][i], P[l+4][i])
                 // adjacent -- four 16-byte loads per entry, those of three entries in flight before the first is used
                 const int n = NS * 8;
-                for (int base = 0; base < n; base += 192) {
+                for (int base = 0; base < n; base += 3 * NT) {
                     double2 pr[3][4];
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
-                        const int e = min(base + 64 * q + lane, n - 1), k = e >> 3, i = e & 7;
+                        const int e = min(base + NT * q + tid, n - 1), k = e >> 3, i = e & 7;
 #pragma unroll
                         for (int l = 0; l < 4; l++) pr[q][l] = *reinterpret_cast<const double2 *>(Pg + (size_t)k * 64 + RIC_IDX(l, i));
                     }
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
-                        const int e = base + 64 * q + lane, ec = min(e, n - 1), k = ec >> 3;
+                        const int e = base + NT * q + tid, ec = min(e, n - 1), k = ec >> 3;
                         double acc = pv[ec];
 #pragma unroll
                         for (int l = 0; l < 4; l++) { acc = fma(pr[q][l].x, dz[k * 10 + l], acc); acc = fma(pr[q][l].y, dz[k * 10 + l + 4], acc); }
@@ -663,7 +689,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     }
                 }
             }
-            WSYNC();
+            BSYNC();
 
 /*@S:11*/
             // ---- slack / multiplier steps, step length ----
@@ -726,7 +752,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 /*@S:15*/
             // hard sides collect max(-dt/t), max(-dlam/lam) (>= 1 matters only); soft sides the step bounds themselves
             if (NSOFT == 0) { amax = fmin(amax, 1.0 / rmax); amax_d = fmin(amax_d, 1.0 / rmax_d); }
-            amax = wave_min(amax); amax_d = wave_min(amax_d);
+            amax = blk_min(amax); amax_d = blk_min(amax_d);
             if (pass == 0) {
                 if (a.m_act == 0) { alpha = alpha_d = 1.0; break; }
 #pragma unroll
@@ -741,18 +767,18 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                         mu_aff += (so_ls[q] + amax_d * so_dls[q]) * (so_s[q] + amax * so_ds[q]);
                     }
                 }
-                mu_aff = wave_sum(mu_aff) * inv_m;
+                mu_aff = blk_sum(mu_aff) * inv_m;
                 const double ratio = (mu > 0.0) ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
             } else {
                 alpha = fmin(1.0, 0.995 * amax); alpha_d = fmin(1.0, 0.995 * amax_d);
             }
-            WSYNC();
+            BSYNC();
         }
 /*@S:12*/
         if (fmin(alpha, alpha_d) < 1e-12) { qstatus = 2; break; }
-        for (int e = lane; e < NS * 10; e += 64) z[e] = fma(alpha, dz[e], z[e]);
-        for (int e = lane; e < NS * 8; e += 64) pi[e] = fma(alpha_d, pv[e], pi[e]);
+        for (int e = tid; e < NS * 10; e += NT) z[e] = fma(alpha, dz[e], z[e]);
+        for (int e = tid; e < NS * 8; e += NT) pi[e] = fma(alpha_d, pv[e], pi[e]);
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
@@ -760,7 +786,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (fin(s_du[r])) { lam_u[r] = fma(alpha_d, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
             if (IS_SOFT(r)) { const int q = r < NSOFT ? r : 0; so_s[q] = fma(alpha, so_ds[q], so_s[q]); so_ls[q] = fma(alpha_d, so_dls[q], so_ls[q]); }
         }
-        WSYNC();
+        BSYNC();
     }
     if (qstatus == 1 && !(res_g <= 1e4 * tol_g && res_b <= 1e4 * tol_b && res_d <= 1e4 * tol_d && res_m <= 1e4 * tol_m)) qstatus = 4;
 
@@ -769,24 +795,24 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     int st = 0;
     if (qstatus == 3) st = 1;
     else if (qstatus == 2 || qstatus == 4) st = 4;
-    WSYNC();
+    BSYNC();
     if (st == 0) {
         double bad = 0.0;
-        for (int e = lane; e < NS * 10; e += 64) bad = fmax(bad, isfinite(z[e]) ? 0.0 : 1.0);
-        if (wave_max(bad) > 0.0) st = 1;
+        for (int e = tid; e < NS * 10; e += NT) bad = fmax(bad, isfinite(z[e]) ? 0.0 : 1.0);
+        if (blk_max(bad) > 0.0) st = 1;
     }
     double *xw = a.x + (size_t)b * NS * 8, *uw = a.u + (size_t)b * N * 2;
     if (NSOFT > 0) {        // slacks of a failed instance read 0; an all-hard table never touches the array
-        for (int e = lane; e < NS * 28; e += 64) slkb[e] = 0.0;
+        for (int e = tid; e < NS * 28; e += NT) slkb[e] = 0.0;
     }
     if (st == 0) {
-        for (int e = lane; e < NS * 10; e += 64) {
+        for (int e = tid; e < NS * 10; e += NT) {
             const int k = e / 10, j = e % 10;
             if (j < 8) xw[k * 8 + j] += z[e];
             else if (k < N) uw[k * 2 + j - 8] += z[e];
         }
-        for (int e = lane; e < NS * 8; e += 64) pib[e] = (e < 8) ? 0.0 : pi[e];
-        for (int e = lane; e < NS * 28; e += 64) lamb[e] = 0.0;
+        for (int e = tid; e < NS * 8; e += NT) pib[e] = (e < 8) ? 0.0 : pi[e];
+        for (int e = tid; e < NS * 28; e += NT) lamb[e] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
@@ -798,8 +824,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         }
     }
     __syncthreads();
-    if (lane < 2) a.u0[(size_t)b * 2 + lane] = uw[lane];
-    if (lane == 0) {
+    if (tid < 2) a.u0[(size_t)b * 2 + tid] = uw[tid];
+    if (tid == 0) {
         a.status[b] = st; a.qp_iter[b] = it;
         // the QP's own KKT residuals where the iteration stopped, relative to the scales its tolerance is taken against
         // (stationarity, dynamics, inequalities, complementarity: <= ipm_tol each for status 0)
@@ -808,6 +834,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     }
 }
 
+#undef BSYNC
+
 template <int NSLOT, int NSOFT, int PATH, int UNI>
 __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
 {
@@ -815,6 +843,18 @@ __global__ __launch_bounds__(64) void k_qp_wave(QpArgs a)
     if ((int)blockIdx.x >= a.B) return;
     qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, blockIdx.x, sm);
 }
+
+// The latency kernel: NW wavefronts per instance (qp_wave_body with NW > 1), for batches that leave most of the chip idle -- the
+// reference's own use is ONE car at 20 Hz.  Each wave sits on its own SIMD of the CU and keeps the full register budget.
+#if QP_SET == 0
+template <int NSLOT, int UNI, int NW>
+__global__ __launch_bounds__(64 * NW) void k_qp_block(QpArgs a)
+{
+    extern __shared__ double sm[];
+    if ((int)blockIdx.x >= a.B) return;          // block-uniform
+    qp_wave_body<NSLOT, 0, 0, UNI, NW>(a, blockIdx.x, sm);
+}
+#endif
 
 // ---- persistent per-instance loop: n_steps control steps of the MiL loop (python/main.py:476-517) in ONE launch ----
 // A wavefront owns an instance and runs, step after step,  [lap wrap] -> plant (lane 0) -> reference ramp + warm-start shift
@@ -1096,6 +1136,18 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
         }                                                                                                                 \
     } while (0)
 #if QP_SET == 0
+    // few instances (at most one per CU): four wavefronts per instance, slots from the 256-lane table
+    if (h->block_qp && nsoft == 0 && !h->path_on && h->nslot_lane_blk >= 1 && h->nslot_lane_blk <= 2 && h->B <= h->n_cu) {
+        a.slot_kc = h->slot_kc_blk; a.slot_lb = h->slot_lb_blk; a.slot_ub = h->slot_ub_blk; a.nslots = h->nslot_lane_blk * 256;
+        if (uni) {
+            (void)hipFuncSetAttribute((const void *)k_qp_block<2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_qp_block<2, 1, 4>), dim3(h->B), dim3(256), lds, h->stream, a);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_qp_block<2, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_qp_block<2, 0, 4>), dim3(h->B), dim3(256), lds, h->stream, a);
+        }
+        return 0;
+    }
     if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0, 0);
     else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0, 0);
     else return 2;

@@ -93,17 +93,18 @@ struct RicLds {
 // loads itself across the stores in between).  What bounds the phase is the number of cache lines its scattered loads touch (a
 // lane's row / column of [A B] lies in other lines than its neighbour's); staging the records through LDS with coalesced loads
 // was tried and lost to LDS bank conflicts (rows 64 bytes apart: 16-way), measured 29 k cycles against 10 k.
-template <int NB>
+// NT: threads that share the pass (64 for a wavefront per instance, 64 NW for the block kernel); lane = thread index among them
+template <int NB, int NT = 64>
 __device__ __forceinline__ void dyn_residual(const int N, const int lane, double *linb, const double *z, const double *pi, double *gt, double *rb,
                                              const int lin_rec)
 {
     const int n1 = N * 8;
-    for (int base = 0; base < n1; base += 64 * NB) {
+    for (int base = 0; base < n1; base += NT * NB) {
         double2 Ar[NB][4], Br[NB];
         double br[NB];
 #pragma unroll
         for (int q = 0; q < NB; q++) {
-            const int e = min(base + 64 * q + lane, n1 - 1), k = e >> 3, o = e & 7;
+            const int e = min(base + NT * q + lane, n1 - 1), k = e >> 3, o = e & 7;
             const double *rec = linb + (size_t)k * lin_rec;
             const double2 *row = reinterpret_cast<const double2 *>(rec + o * 8);
 #pragma unroll
@@ -113,7 +114,7 @@ __device__ __forceinline__ void dyn_residual(const int N, const int lane, double
         }
 #pragma unroll
         for (int q = 0; q < NB; q++) {
-            const int e = base + 64 * q + lane, ec = min(e, n1 - 1), k = ec >> 3, o = ec & 7;
+            const int e = base + NT * q + lane, ec = min(e, n1 - 1), k = ec >> 3, o = ec & 7;
             double acc = br[q] - z[(k + 1) * 10 + o];
 #pragma unroll
             for (int l = 0; l < 4; l++) { acc = fma(Ar[q][l].x, z[k * 10 + 2 * l], acc); acc = fma(Ar[q][l].y, z[k * 10 + 2 * l + 1], acc); }
@@ -126,11 +127,11 @@ __device__ __forceinline__ void dyn_residual(const int N, const int lane, double
         }
     }
     const int n2 = N * 10;
-    for (int base = 0; base < n2; base += 64 * NB) {
+    for (int base = 0; base < n2; base += NT * NB) {
         double cr[NB][8];
 #pragma unroll
         for (int q = 0; q < NB; q++) {
-            const int e = min(base + 64 * q + lane, n2 - 1), k = e / 10, jz = e - k * 10;
+            const int e = min(base + NT * q + lane, n2 - 1), k = e / 10, jz = e - k * 10;
             const double *rec = linb + (size_t)k * lin_rec;
             const double *col = (jz < 8) ? rec + jz : rec + 64 + (jz - 8);
             const int cs = (jz < 8) ? 8 : 2;
@@ -139,7 +140,7 @@ __device__ __forceinline__ void dyn_residual(const int N, const int lane, double
         }
 #pragma unroll
         for (int q = 0; q < NB; q++) {
-            const int e = base + 64 * q + lane, ec = min(e, n2 - 1), k = ec / 10;
+            const int e = base + NT * q + lane, ec = min(e, n2 - 1), k = ec / 10;
             double acc = gt[ec];
 #pragma unroll
             for (int l = 0; l < 8; l++) acc = fma(cr[q][l], pi[(k + 1) * 8 + l], acc);

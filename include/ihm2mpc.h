@@ -252,7 +252,9 @@ int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps);
 /* n_steps control steps of the MiL loop (python/main.py:476-517: plant, reference ramp + shift, one RTI iteration) in ONE
  * launch: every instance runs its steps back to back on its own wavefront, so no instance waits for the slowest QP of the
  * batch at every step (throughput follows the mean interior-point iteration count instead of the maximum).  Results are
- * those of n_steps calls of ihm2mpc_step -- bit for bit for batches of more than 3 instances; ihm2mpc_step, ihm2mpc_solve and
+ * those of n_steps calls of ihm2mpc_step -- bit for bit where both take the single-wave QP kernel and the batch linearisation, i.e.
+ * for batches of more than one instance per compute unit; smaller batches take the latency kernels in ihm2mpc_step (four wavefronts
+ * per instance in the QP -- the environment variable IHM2MPC_BLOCK_QP=0 turns that off --, results equal to 1e-9); ihm2mpc_step, ihm2mpc_solve and
  * ihm2mpc_compute_control linearise batches of up to 128 intervals (batch <= 3 at N = 40) one sensitivity column per wavefront
  * (the latency path of the single real-time controller), whose records agree with the loop's to 1e-15, not bit for bit.  The persistent loop exists for the fkin6 OCP -- all-hard constraint tables (the
  * reference's OCP) and soft / track-row tables with batch-shared weights and rows, in the RTI and the SQP mode --

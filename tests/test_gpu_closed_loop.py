@@ -162,11 +162,15 @@ LIVE = dict(nlp_solver_type="SQP", nlp_solver_max_iter=2, globalization="MERIT_B
 
 
 @pytest.mark.parametrize("plant,n_max,B,opts", [(0, 2.0, 150, {}), (-1, 0.9, 150, {}), (0, 2.0, 1100, {}), (0, 2.0, 150, LIVE), (-1, 2.0, 70, LIVE)])
-def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts):
+def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts, monkeypatch):
     """ihm2mpc_run_steps (every instance runs its control steps back to back on its own wavefront, one launch) gives the
     results of the same number of ihm2mpc_step calls: same device functions, same order per instance.  B = 1100 does not fit
-    the device at once: run_steps then launches per step internally."""
+    the device at once: run_steps then launches per step internally.  Bit for bit with the single-wave QP kernel on both sides
+    (IHM2MPC_BLOCK_QP=0: for batches of at most one instance per CU the per-step path otherwise takes the four-wave latency
+    kernel, whose sums run in another order -- test_block_qp_kernel_* covers that one)."""
     from ihm2_amd.solver import BatchedOcpSolver
+
+    monkeypatch.setenv("IHM2MPC_BLOCK_QP", "0")
 
     steps = 12
     x0 = sample_x0(track, B, seed=31)
@@ -201,8 +205,10 @@ def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts):
         assert (ha["status"] == 0).mean() > (0.9 if plant == 0 else 0.7)      # n_max 0.9 with the dynamic plant: some QPs are infeasible
 
 
-def test_persistent_closed_loop_equals_the_device_loop(track):
-    """run_closed_loop_persistent (freezing rules on the device, one launch) reproduces run_closed_loop_device."""
+def test_persistent_closed_loop_equals_the_device_loop(track, monkeypatch):
+    """run_closed_loop_persistent (freezing rules on the device, one launch) reproduces run_closed_loop_device (single-wave QP kernel
+    on both sides, see test_persistent_loop_equals_step_by_step)."""
+    monkeypatch.setenv("IHM2MPC_BLOCK_QP", "0")
     from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop_device, run_closed_loop_persistent
     from ihm2_amd.controller import IHM2Controller
 
@@ -299,3 +305,50 @@ def test_persistent_loop_with_soft_tables_equals_step_by_step(track, variant, op
     np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
     np.testing.assert_array_equal(la, lb); np.testing.assert_array_equal(sa, sb)
     assert np.isin(ha["status"], (0, 2) if opts else (0,)).mean() > 0.8 and sa.max() > 1e-4          # solved, and slack is really used
+
+
+@pytest.mark.parametrize("B", [1, 3, 96, 256])
+def test_block_qp_kernel_matches_the_single_wave_kernel_and_the_oracle(track, B, monkeypatch):
+    """k_qp_block (four wavefronts per instance, taken for batches of at most one instance per CU): the same statuses and IPM
+    iteration counts as the single-wave kernel, iterates equal to 1e-9 (the sums run in another order), and the oracle's within the
+    parity tolerance; 6 closed-loop steps."""
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    x0 = sample_x0(track, B, seed=41)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("IHM2MPC_BLOCK_QP", mode)
+        ocp = make_ocp()
+        s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+        s.set_lap_wrap(True); s.set_x0(x0); s.init_guess()
+        yref = np.zeros((B, 40, 12)); yref[:, :, 0] = x0[:, 0:1] + 40.0 * np.arange(40)[None] / 40
+        yref_e = np.zeros((B, 8)); yref_e[:, 0] = x0[:, 0] + 40.0
+        s.set_yref(yref); s.set_yref_e(yref_e); s.set_multipliers(None, None)
+        x_in, u_in = s.get_x(), s.get_u()
+        st = s.solve()
+        first = dict(status=st.copy(), it=s.get_qp_iter().copy(), x=s.get_x(), u=s.get_u(), res=s.get_qp_residuals())
+        hist = []
+        for _ in range(6):
+            s.step(40.0, model=0, M_sim=25)
+            hist.append((s.get_status().copy(), s.get_qp_iter().copy(), s.get_u0().copy()))
+        res[mode] = (first, hist)
+        if mode == "1":
+            P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+            xo, uo = x_in.copy(), u_in.copy()
+            out = P.rti_step(xo, uo, x0, yref, yref_e)
+            np.testing.assert_array_equal(st, out["status"])
+            ok = st == 0
+            assert np.mean(first["it"][ok] == out["qp_iter"][ok]) >= 0.97
+            assert np.max(np.abs(first["x"][ok] - xo[ok]) / np.maximum(1.0, np.abs(xo[ok]))) < 1e-6           # tolerance 1e-6 relative
+            assert np.max(np.abs(first["u"][ok] - uo[ok]) / np.maximum(1.0, np.abs(uo[ok]))) < 1e-6
+            assert np.all(first["res"][ok] <= 1e-6)
+        s.free()
+    (fa, ha), (fb, hb) = res["1"], res["0"]
+    np.testing.assert_array_equal(fa["status"], fb["status"])
+    assert np.mean(fa["it"] == fb["it"]) >= 0.97
+    assert np.max(np.abs(fa["x"] - fb["x"]) / np.maximum(1.0, np.abs(fb["x"]))) < 1e-7
+    for (sa, ia, ua), (sb_, ib, ub) in zip(ha, hb):
+        assert np.mean(sa == sb_) >= 0.98 and np.mean(ia == ib) >= 0.9
+        ok = (sa == 0) & (sb_ == 0)
+        assert np.max(np.abs(ua[ok] - ub[ok]) / np.maximum(1.0, np.abs(ub[ok]))) < 1e-5      # closed loop: rounding differences are fed back for six steps
