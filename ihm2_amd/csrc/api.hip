@@ -201,7 +201,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
-                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc,
+                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc, h->ls_pending,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
@@ -658,7 +658,17 @@ static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
                 HIP_TRY(hipMalloc((void **)&h->ls_phi, (size_t)n_alpha * B * N * 8 * sizeof(double)));
                 h->ls_nalpha = n_alpha;
             }
-            ihm2_launch_rollout_irk(h, n_alpha, h->ls_phi);
+            if (!h->ls_pending) HIP_TRY(hipMalloc((void **)&h->ls_pending, (size_t)B * sizeof(int32_t)));
+            // most instances accept one of the first step lengths: those rollouts for everybody, the rest of the ladder only for the
+            // instances the first line-search launch leaves open (which then redo their ladder: same arithmetic as one launch)
+            const int j_first = n_alpha < 3 ? n_alpha : 3;
+            ihm2_launch_rollout_irk(h, 0, j_first, h->ls_phi, nullptr);
+            if (j_first < n_alpha) {
+                ihm2_launch_line_search(h, it, it == n_iter - 1, 1, j_first);
+                ihm2_launch_rollout_irk(h, j_first, n_alpha, h->ls_phi, h->ls_pending);
+                ihm2_launch_line_search(h, it, it == n_iter - 1, 2, 0);
+                continue;
+            }
         }
         ihm2_launch_line_search(h, it, it == n_iter - 1);
     }

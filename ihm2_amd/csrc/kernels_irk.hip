@@ -345,17 +345,20 @@ __global__ __launch_bounds__(64) void k_sim_irk(int B, int model, int M, IrkTab 
 // has one lane per stage; the collocation step wants four, so its rollouts are done here, all trial points at once (an instance
 // rarely needs more than the first: the rest is cheap insurance against a second launch per backtrack).
 template <int MODEL>
-__global__ __launch_bounds__(64) void k_rollout_irk(int B, int N, int M, int n_alpha, double alpha_red, IrkTab tab, int nknots, const double *__restrict__ s_ref,
+__global__ __launch_bounds__(64) void k_rollout_irk(int B, int N, int M, int j_begin, int j_end, const int32_t *__restrict__ pending, double alpha_red, IrkTab tab, int nknots, const double *__restrict__ s_ref,
                                                     const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *__restrict__ x,
                                                     const double *__restrict__ u, const double *__restrict__ xp, const double *__restrict__ up, double *phi)
 {
-    const long total = (long)n_alpha * B * N;
+    // quads are numbered instance-major within a step length; pending: only the instances the first line-search launch left open
+    const long total = (long)(j_end - j_begin) * B * N;
     const long q = (long)blockIdx.x * 16 + (threadIdx.x >> 2);
-    const long pr = min(q, total - 1);
+    const long pl = min(q, total - 1);
     const int st = threadIdx.x & 3;
-    const int j = (int)(pr / ((long)B * N));
-    const long rem = pr - (long)j * B * N;
+    const int j = j_begin + (int)(pl / ((long)B * N));
+    const long rem = pl - (long)(j - j_begin) * B * N;
     const int b = (int)(rem / N), k = (int)(rem % N);
+    if (pending && !pending[b]) return;         // the whole quad leaves together
+    const long pr = (long)j * B * N + rem;
     double al = 1.0;
     for (int jj = 0; jj < j; jj++) al *= alpha_red;          // the very products the line search forms
     const size_t ex = ((size_t)b * (N + 1) + k) * 8, eu = ((size_t)b * N + k) * 2;
@@ -435,12 +438,12 @@ void ihm2_launch_linearize_irk(ihm2mpc_handle *h)
 #undef LAUNCH_IRK
 }
 
-void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int n_alpha, double *phi)
+void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int j_begin, int j_end, double *phi, const int32_t *pending)
 {
-    const long total = (long)n_alpha * h->B * h->N;
+    const long total = (long)(j_end - j_begin) * h->B * h->N;
     const int blocks = (int)((total + 15) / 16);
     const IrkTab tab = make_tab(h->cfg.integrator_type, h->cfg.dt / h->cfg.M);
-#define LAUNCH_RO(MD) hipLaunchKernelGGL(k_rollout_irk<MD>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, n_alpha, h->sqp_alpha_red, tab, h->cfg.nknots, \
+#define LAUNCH_RO(MD) hipLaunchKernelGGL(k_rollout_irk<MD>, dim3(blocks), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, j_begin, j_end, pending, h->sqp_alpha_red, tab, h->cfg.nknots, \
                                          h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->ls_x, h->ls_u, phi)
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U) LAUNCH_RO(IHM2MPC_MODEL_FDYN6U);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6) LAUNCH_RO(IHM2MPC_MODEL_FDYN6);

@@ -31,10 +31,12 @@ __global__ __launch_bounds__(64) void k_line_search(LsArgs a, int it, int last)
 
 }  // namespace
 
-// it: SQP iteration index of this solve (0 resets the per-solve counters on the host side), last: it == max_iter - 1
-void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last)
+// it: SQP iteration index of this solve (0 resets the per-solve counters on the host side), last: it == max_iter - 1;
+// phase / j_limit: LsArgs (the ladder in two launches for the collocation integrator)
+void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last, int phase, int j_limit)
 {
-    const LsArgs a = make_ls_args(h);
+    LsArgs a = make_ls_args(h);
+    a.phase = phase; a.j_limit = j_limit;
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U) hipLaunchKernelGGL(k_line_search<IHM2MPC_MODEL_FDYN6U>, dim3(h->B), dim3(64), 0, h->stream, a, it, last);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6) hipLaunchKernelGGL(k_line_search<IHM2MPC_MODEL_FDYN6>, dim3(h->B), dim3(64), 0, h->stream, a, it, last);
     else hipLaunchKernelGGL(k_line_search<IHM2MPC_MODEL_FKIN6>, dim3(h->B), dim3(64), 0, h->stream, a, it, last);

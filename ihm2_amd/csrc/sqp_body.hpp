@@ -27,6 +27,11 @@ struct LsArgs {
     double *alpha, *u0;
     const double *phi;               // IRK: Phi at the trial points, (n_alpha, B, N, 8), from k_rollout_irk; nullptr: RK4 rollouts in this kernel
     int n_alpha;
+    // the ladder in two launches (IRK): phase 1 tries the first j_limit step lengths and marks the instances that need more in
+    // `pending` without touching their iterate; phase 2 redoes the ladder of exactly those (same arithmetic, all rollouts present);
+    // phase 0: one launch, the whole ladder
+    int phase, j_limit;
+    int32_t *pending;
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -89,6 +94,10 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
     };
 
     // everything below is wave-uniform
+    const bool resume = a.phase == 2;       // the bookkeeping and the merit weights of this iteration were done by phase 1
+    if (resume && !a.pending[b]) return;
+    if (a.phase == 1 && lane == 0) a.pending[b] = 0;
+    if (!resume) {
     if (a.done[b]) { restore(true); finish(a.sqp_status[b]); return; }
     const int qst = a.status[b];
     if (lane == 0) a.qp_acc[b] += a.qp_iter[b];
@@ -134,6 +143,7 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
             const double m = fabs(lamb[e]);
             wlamb[e] = (it == 0) ? m : fmax(m, 0.5 * (wlamb[e] + m));
         }
+    }
     }
     __syncthreads();
 
@@ -263,6 +273,10 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
     }
     double al = 1.0;
     for (int jtrial = 0;; jtrial++) {              // at most log(alpha_min) / log(alpha_red) + 1 trials: al shrinks every pass
+        if (a.phase == 1 && jtrial >= a.j_limit) {      // rollouts beyond this one are not there yet: phase 2 takes this instance
+            if (lane == 0) a.pending[b] = 1;
+            return;
+        }
         double c1, i1;
         merit(al, jtrial, false, c1, i1);
         const double m1 = c1 + i1;
@@ -307,6 +321,7 @@ static inline LsArgs make_ls_args(ihm2mpc_handle *h)
     a.done = h->ls_done; a.sqp_status = h->ls_status; a.sqp_iter = h->ls_iter; a.qp_acc = h->ls_qp_acc;
     a.alpha = h->ls_alpha; a.u0 = h->u0;
     a.phi = (h->cfg.integrator_type != IHM2MPC_INTEG_ERK) ? h->ls_phi : nullptr; a.n_alpha = h->ls_nalpha;
+    a.phase = 0; a.j_limit = 0; a.pending = h->ls_pending;
     return a;
 }
 
