@@ -136,14 +136,15 @@ def test_converged_instances_are_left_alone_and_report_status_0(track):
 @pytest.mark.parametrize("model", ["fkin6", "fdyn6u"])
 def test_live_solver_options_sqp_with_irk_match_oracle(track, model):
     """python/main.py:227-238 as the reference runs it: SQP, two iterations, MERIT_BACKTRACKING, IRK with four Gauss-Legendre stages and
-    one step per interval.  The line search's trial points are integrated by k_rollout_irk (all step lengths of the ladder in one
-    launch); one SQP iteration per call with both sides re-synchronised in between, as above."""
+    one step per interval.  The line search's trial points are integrated by k_rollout_irk (the first three step lengths for all
+    instances, the rest of the ladder for the instances the first line-search launch leaves open); one SQP iteration per call with both
+    sides re-synchronised in between, as above."""
     B = 66
     s, P, data, x0, yref, yref_e = _setup(track, model, "hard", B, 31, nlp_solver_max_iter=1, integrator_type="IRK", sim_method_num_steps=1)
     assert data.integrator != 0
     x, u = s.get_x(), s.get_u()
     pi = np.zeros((B, N + 1, 8)); lam = np.zeros((B, N + 1, 28)); sl = np.zeros((B, N + 1, 28))
-    n_short = 0
+    n_short = n_deep = 0
     for it in range(3):
         status = s.solve()
         out = P.sqp_solve(x, u, x0, yref, yref_e, pi=pi, lam=lam, sl=sl, max_iter=1, tol=data.sqp_tol)
@@ -154,11 +155,13 @@ def test_live_solver_options_sqp_with_irk_match_oracle(track, model):
         same = both & (np.abs(st["alpha"] - out["alpha"]) < 1e-12)
         assert same.sum() >= 0.95 * both.sum()
         n_short += int((out["alpha"][both] < 1.0).sum())
+        n_deep += int((out["alpha"][same] < 0.7 ** 2 - 1e-9).sum())      # past the third trial: settled by the second pair of launches
         assert _rel(s.get_x()[same], x[same]) < 1e-6 and _rel(s.get_u()[same], u[same]) < 1e-6          # tolerance 1e-6 relative
         s.set_x(x); s.set_u(u); s.set_multipliers(pi, lam); s.set_slacks(sl)
         if model == "fkin6":
             assert both.sum() >= 0.9 * B
     assert n_short >= 1
+    assert n_deep >= 1          # the second pair of launches is exercised (and agreed with the oracle's step length to 1e-12)
     # two iterations inside one solve (the live max_iter = 2): runs, and every instance ends in an accepted status or a reported failure
     s2, _, _, _, _, _ = _setup(track, model, "hard", B, 31, nlp_solver_max_iter=2, integrator_type="IRK", sim_method_num_steps=1)
     st2 = s2.solve()
