@@ -188,6 +188,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(lin, (B * N + B) * LIN_REC);      // + one spare record per instance (the kinematic plant's, never read)
     DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, (B * N + 2 * QM_PAD) * 64); DA(scratch, B * 24);
 #undef DA
+    if (ihm2_upload_irk_tab(h)) return fail("could not upload the collocation tableau");
     *out = h;
     return 0;
 }
@@ -201,7 +202,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
-                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc, h->ls_pending,
+                    h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc, h->ls_pending, h->irk_tab,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete[] h->host_lb; delete[] h->host_ub; delete[] h->host_sz; delete[] h->host_sZ;
@@ -627,6 +628,24 @@ static int sqp_buffers(ihm2mpc_handle *h)
     return 0;
 }
 
+// SQP mode with the collocation integrator: room for the line search's trial-point rollouts (every step length of the ladder)
+static int sqp_phi_buffer(ihm2mpc_handle *h, int *n_alpha_out)
+{
+    const size_t B = h->B, N = h->N;
+    int n_alpha = 1;
+    for (double al = h->sqp_alpha_red; al >= h->sqp_alpha_min && n_alpha < 64; al *= h->sqp_alpha_red) n_alpha++;
+    if (!h->ls_phi || h->ls_nalpha < n_alpha) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->ls_phi) (void)hipFree(h->ls_phi);
+        h->ls_phi = nullptr;
+        HIP_TRY(hipMalloc((void **)&h->ls_phi, (size_t)n_alpha * B * N * 8 * sizeof(double)));
+        h->ls_nalpha = n_alpha;
+    }
+    if (!h->ls_pending) HIP_TRY(hipMalloc((void **)&h->ls_pending, (size_t)B * sizeof(int32_t)));
+    if (n_alpha_out) *n_alpha_out = n_alpha;
+    return 0;
+}
+
 // SQP mode: n_iter iterations of [copy the iterate aside -> linearise -> QP -> convergence test + line search].  join: the first
 // QP waits for ev_join (ihm2mpc_step runs the plant and the reference ramp beside the first linearisation).
 static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
@@ -650,15 +669,7 @@ static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
         if (h->cfg.integrator_type != IHM2MPC_INTEG_ERK && h->sqp_globalization) {
             // collocation integrator: the rollouts of the line search's trial points (all step lengths of the ladder) in their own launch
             int n_alpha = 1;
-            for (double al = h->sqp_alpha_red; al >= h->sqp_alpha_min && n_alpha < 64; al *= h->sqp_alpha_red) n_alpha++;
-            if (!h->ls_phi || h->ls_nalpha < n_alpha) {
-                HIP_TRY(hipStreamSynchronize(h->stream));
-                if (h->ls_phi) (void)hipFree(h->ls_phi);
-                h->ls_phi = nullptr;
-                HIP_TRY(hipMalloc((void **)&h->ls_phi, (size_t)n_alpha * B * N * 8 * sizeof(double)));
-                h->ls_nalpha = n_alpha;
-            }
-            if (!h->ls_pending) HIP_TRY(hipMalloc((void **)&h->ls_pending, (size_t)B * sizeof(int32_t)));
+            if (sqp_phi_buffer(h, &n_alpha)) return -1;
             // most instances accept one of the first step lengths: those rollouts for everybody, the rest of the ladder only for the
             // instances the first line-search launch leaves open (which then redo their ladder: same arithmetic as one launch)
             const int j_first = n_alpha < 3 ? n_alpha : 3;
@@ -973,6 +984,7 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
     const bool resident = B <= (size_t)4 * h->n_cu;
     int rc = 1;
     if (h->cfg.nlp_solver_type == IHM2MPC_SQP && sqp_buffers(h)) return -1;
+    if (h->cfg.nlp_solver_type == IHM2MPC_SQP && h->cfg.integrator_type != IHM2MPC_INTEG_ERK && h->sqp_globalization && sqp_phi_buffer(h, nullptr)) return -1;
     if (resident) {
         HIP_TRY(hipEventRecord(h->ev[0], h->stream));
         HIP_TRY(hipEventRecord(h->ev[1], h->stream));

@@ -16,232 +16,11 @@
 #include "device_steps.hpp"
 #include "riccati_mfma.hpp"
 #include "irk_tableaux.h"
+#include "irk_body.hpp"
 
 using namespace ihm2;
 
 namespace {
-
-struct IrkTab {
-    double A[4][4], b[4];
-    double invT[4][4], invD[4][4];      // (I + h/t_T A)^-1, (I + h/t_delta A)^-1
-    double h;
-};
-
-// what a lane needs of the tableau: row st of A and of the two inverse actuator blocks, h and h b_st.  Extracted ONCE per kernel with
-// constant indices: the kernel-argument struct must not have its address taken (the compiler would copy it to scratch)
-struct IrkRows {
-    double Arow[4], invT[4], invD[4], h, hb;
-};
-#define IRK_ROWS(R, tab, st)                                                                                                  \
-    IrkRows R;                                                                                                                 \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) {                                                                        \
-        R.Arow[j_] = ((st) == 0) ? tab.A[0][j_] : ((st) == 1) ? tab.A[1][j_] : ((st) == 2) ? tab.A[2][j_] : tab.A[3][j_];           \
-        R.invT[j_] = ((st) == 0) ? tab.invT[0][j_] : ((st) == 1) ? tab.invT[1][j_] : ((st) == 2) ? tab.invT[2][j_] : tab.invT[3][j_]; \
-        R.invD[j_] = ((st) == 0) ? tab.invD[0][j_] : ((st) == 1) ? tab.invD[1][j_] : ((st) == 2) ? tab.invD[2][j_] : tab.invD[3][j_]; \
-    }                                                                                                                          \
-    R.h = tab.h;                                                                                                               \
-    R.hb = tab.h * (((st) == 0) ? tab.b[0] : ((st) == 1) ? tab.b[1] : ((st) == 2) ? tab.b[2] : tab.b[3]);
-
-// row st of a 4 x 4 table that arrives as a kernel argument: selects with constant indices (a lane-dependent index would make the
-// compiler copy the argument block to scratch)
-__device__ __forceinline__ double tab_row(const double (&Tm)[4][4], int st, int j)
-{
-    return (st == 0) ? Tm[0][j] : (st == 1) ? Tm[1][j] : (st == 2) ? Tm[2][j] : Tm[3][j];
-}
-
-// value of lane j of this lane's quad
-template <int J>
-__device__ __forceinline__ double quad_bcast(double v)
-{
-    return dpp_mov<J | (J << 2) | (J << 4) | (J << 6)>(v);
-}
-__device__ __forceinline__ double quad_sum(double v)
-{
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    return v;
-}
-__device__ __forceinline__ double quad_get(double v, int j)      // j is a compile-time constant after unrolling
-{
-    return (j == 0) ? quad_bcast<0>(v) : (j == 1) ? quad_bcast<1>(v) : (j == 2) ? quad_bcast<2>(v) : quad_bcast<3>(v);
-}
-
-// Gauss-Jordan on a 12 x 12 block distributed over the quad: lane i holds rows (i, 0..2) = Mr[3][12] and NR right-hand sides
-// R[3][NR]; unknown (j, b) is column 3 j + b.  On return R holds the solution rows of this lane's stage.
-template <int NR>
-__device__ __forceinline__ void quad_solve12(const int st, double (&Mr)[3][12], double (&R)[3][NR])
-{
-    // (inner loops over all 12 columns with the condition c > p inside: trip counts that depend on p kept the compiler from
-    // unrolling them, and the matrix went to scratch memory)
-#pragma unroll
-    for (int p = 0; p < 12; p++) {
-        const int pj = p / 3, pb = p % 3;                 // the pivot row: local row pb of the lane that owns stage pj
-        const bool owner = st == pj;
-        const double ipiv = 1.0 / quad_get(Mr[pb][p], pj);
-        double prow[12], prhs[NR];
-#pragma unroll
-        for (int c = 0; c < 12; c++) prow[c] = (c > p) ? quad_get(Mr[pb][c], pj) * ipiv : 0.0;
-#pragma unroll
-        for (int c = 0; c < NR; c++) prhs[c] = quad_get(R[pb][c], pj) * ipiv;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const bool is_piv = owner && r == pb;
-            const double f = is_piv ? 0.0 : Mr[r][p];
-#pragma unroll
-            for (int c = 0; c < 12; c++)
-                if (c > p) Mr[r][c] = is_piv ? prow[c] : fma(-f, prow[c], Mr[r][c]);
-#pragma unroll
-            for (int c = 0; c < NR; c++) R[r][c] = is_piv ? prhs[c] : fma(-f, prhs[c], R[r][c]);
-        }
-    }
-}
-
-// structural non-zeros of the model Jacobian (model.hpp: JX_MASK / JU_MASK): with constant indices the test folds at compile time, so
-// the zero entries cost neither arithmetic nor registers (80 Jacobian entries per lane do not fit beside the 12 x 12 block)
-template <int MODEL>
-__device__ __forceinline__ constexpr bool jnz(int a, int c)
-{
-    return (c < 8) ? ((JX_MASK[MODEL ? 1 : 0][a] >> c) & 1u) != 0 : ((JU_MASK[MODEL ? 1 : 0][a] >> (c - 8)) & 1u) != 0;
-}
-
-template <int MODEL>
-__device__ __forceinline__ void eval_model(const double (&X)[8], double u_T, double u_d, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
-{
-    // (structural zeros of J are never written and never read: jnz)
-    if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, f, J);
-    else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, f, J);
-}
-
-// One collocation step of size tab.h from x for the quad (st = this lane's stage).  K: this lane's stage value on return.
-// With SENS: dK[a][c] = d K_st[a] / d (x, u)_c for the incoming sensitivity S (8 x 10, the same in the four lanes).
-// state groups as compile-time index maps (tables in device memory would turn every J[a][G..] into a dynamic index and J into scratch)
-#define G1(q) (6 + (q))
-#define G2(q) (3 + (q))
-#define G3(q) (q)
-
-// Newton iterations of one collocation step from x; K: this lane's stage value, J: the model Jacobian at the final stage point
-// (evaluated only WITH_J, for the sensitivities).
-template <int MODEL, bool WITH_J>
-__device__ __forceinline__ void irk_step(const int st, const IrkRows &tab, const double (&x)[8], double u_T, double u_d, TrackSeg &trk,
-                                         double (&K)[8], double (&J)[8][10])
-{
-    const double h = tab.h;
-    const double (&Arow)[4] = tab.Arow, (&invT)[4] = tab.invT, (&invD)[4] = tab.invD;
-#pragma unroll
-    for (int a = 0; a < 8; a++) K[a] = 0.0;
-    double f[8];
-    for (int it = 0; it <= IHM2MPC_IRK_NEWTON_ITER; it++) {
-        const bool last = it == IHM2MPC_IRK_NEWTON_ITER;      // the last pass only evaluates the Jacobians the sensitivities need
-        if (last && !WITH_J) break;
-        double X[8];
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            double acc = x[a];
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc = fma(h * Arow[j], quad_get(K[a], j), acc);
-            X[a] = acc;
-        }
-        eval_model<MODEL>(X, u_T, u_d, trk, f, J);
-        if (last) break;
-        // ---- Newton step: (I - h A (x) J) d = -(K - f), group by group ----
-        double d[8];      // this lane's part of the step
-        // actuators: constant 4 x 4 blocks
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int a = G1(q);
-            const double r = -(K[a] - f[a]);
-            double acc = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc = fma((a == 6) ? invT[j] : invD[j], quad_get(r, j), acc);
-            d[a] = acc;
-        }
-        // velocities, then pose: 12 x 12 blocks with the coupling to the groups already solved on the right-hand side
-#pragma unroll
-        for (int grp = 0; grp < 2; grp++) {
-            double Mr[3][12], R[3][1];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const int a = grp ? G3(r) : G2(r);
-                double rhs = -(K[a] - f[a]);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    double cpl = 0.0;      // J[a][solved unknowns] . step of stage j
-#pragma unroll
-                    for (int q = 0; q < 2; q++) if (jnz<MODEL>(a, G1(q))) cpl = fma(J[a][G1(q)], quad_get(d[G1(q)], j), cpl);
-                    if (grp)
-#pragma unroll
-                        for (int q = 0; q < 3; q++) if (jnz<MODEL>(a, G2(q))) cpl = fma(J[a][G2(q)], quad_get(d[G2(q)], j), cpl);
-                    rhs = fma(h * Arow[j], cpl, rhs);
-#pragma unroll
-                    for (int bq = 0; bq < 3; bq++) {
-                        const double unit = (j == st && bq == r) ? 1.0 : 0.0;
-                        Mr[r][3 * j + bq] = jnz<MODEL>(a, grp ? G3(bq) : G2(bq)) ? unit - h * Arow[j] * J[a][grp ? G3(bq) : G2(bq)] : unit;
-                    }
-                }
-                R[r][0] = rhs;
-            }
-            quad_solve12<1>(st, Mr, R);
-#pragma unroll
-            for (int r = 0; r < 3; r++) d[grp ? G3(r) : G2(r)] = R[r][0];
-        }
-#pragma unroll
-        for (int a = 0; a < 8; a++) K[a] += d[a];
-    }
-}
-
-// Sensitivity columns COL0 .. COL0 + NCOL - 1 of one collocation step that starts from S = [I 0] (the first and, for the reference's
-// sim_method_num_steps = 1, only step): (I - h A (x) J) dK = [J_x | J_u], J at the final stage values.  dK[a][c]: this lane's stage.
-template <int MODEL, int COL0, int NCOL>
-__device__ __forceinline__ void irk_sens_cols(const int st, const IrkRows &tab, const double (&J)[8][10], double (&dK)[8][NCOL])
-{
-    const double h = tab.h;
-    const double (&Arow)[4] = tab.Arow, (&invT)[4] = tab.invT, (&invD)[4] = tab.invD;
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int a = G1(q);
-#pragma unroll
-        for (int c = 0; c < NCOL; c++) {
-            double acc = 0.0;
-            if (jnz<MODEL>(a, COL0 + c))
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc = fma((a == 6) ? invT[j] : invD[j], quad_get(J[a][COL0 + c], j), acc);
-            dK[a][c] = acc;
-        }
-    }
-#pragma unroll
-    for (int grp = 0; grp < 2; grp++) {
-        double Mr[3][12], R[3][NCOL];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const int a = grp ? G3(r) : G2(r);
-#pragma unroll
-            for (int c = 0; c < NCOL; c++) R[r][c] = jnz<MODEL>(a, COL0 + c) ? J[a][COL0 + c] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-#pragma unroll
-                for (int c = 0; c < NCOL; c++) {
-                    double cpl = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 2; q++) if (jnz<MODEL>(a, G1(q))) cpl = fma(J[a][G1(q)], quad_get(dK[G1(q)][c], j), cpl);
-                    if (grp)
-#pragma unroll
-                        for (int q = 0; q < 3; q++) if (jnz<MODEL>(a, G2(q))) cpl = fma(J[a][G2(q)], quad_get(dK[G2(q)][c], j), cpl);
-                    R[r][c] = fma(h * Arow[j], cpl, R[r][c]);
-                }
-#pragma unroll
-                for (int bq = 0; bq < 3; bq++) {
-                    const double unit = (j == st && bq == r) ? 1.0 : 0.0;
-                    Mr[r][3 * j + bq] = jnz<MODEL>(a, grp ? G3(bq) : G2(bq)) ? unit - h * Arow[j] * J[a][grp ? G3(bq) : G2(bq)] : unit;
-                }
-            }
-        }
-        quad_solve12<NCOL>(st, Mr, R);
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < NCOL; c++) dK[grp ? G3(r) : G2(r)][c] = R[r][c];
-    }
-}
 
 // one quad: interval k of instance b.  Record [A | B | b] as the RK4 kernels write it.
 template <int MODEL>
@@ -255,50 +34,9 @@ __global__ __launch_bounds__(64) void k_linearize_irk(int B, int N, int M, IrkTa
     const int st = threadIdx.x & 3;
     const int b = (int)(pr / N), k = (int)(pr % N);
     const double *xk = xs + ((size_t)b * (N + 1) + k) * 8, *uk = us + ((size_t)b * N + k) * 2;
-    double x[8];
-#pragma unroll
-    for (int a = 0; a < 8; a++) x[a] = xk[a];
-    const double u_T = uk[0], u_d = uk[1];
-    const int tid = track_id[b];
-    TrackSeg trk;
-    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
-    // one step (the reference's sim_method_num_steps = 1, python/main.py:236; ihm2mpc_create refuses IRK with M != 1): S starts
-    // from [I 0], so the right-hand side of the sensitivity system is the Jacobian itself; the ten columns are solved five at a time
-    // (register budget) and written out at once
     (void)M;
     IRK_ROWS(rows, tab, st)
-    const double hb = rows.hb;
-    double K[8], J[8][10];
-    irk_step<MODEL, true>(st, rows, x, u_T, u_d, trk, K, J);
-    double *rec = lin + ((size_t)b * N + k) * LIN_REC;
-    {
-        double dK[8][5];
-        irk_sens_cols<MODEL, 0, 5>(st, rows, J, dK);
-#pragma unroll
-        for (int a = 0; a < 8; a++)
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const double v = ((a == c) ? 1.0 : 0.0) + quad_sum(hb * dK[a][c]);
-                if (live && (a >> 1) == st) rec[a * 8 + c] = v;
-            }
-    }
-    {
-        double dK[8][5];
-        irk_sens_cols<MODEL, 5, 5>(st, rows, J, dK);
-#pragma unroll
-        for (int a = 0; a < 8; a++)
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const int cc = 5 + c;
-                const double v = ((a == cc) ? 1.0 : 0.0) + quad_sum(hb * dK[a][c]);
-                if (live && (a >> 1) == st) { if (cc < 8) rec[a * 8 + cc] = v; else rec[64 + a * 2 + (cc - 8)] = v; }
-            }
-    }
-#pragma unroll
-    for (int a = 0; a < 8; a++) {
-        const double xn = x[a] + quad_sum(hb * K[a]);
-        if (live && (a >> 1) == st) rec[80 + a] = xn - xk[8 + a];
-    }
+    irk_linearize_quad<MODEL>(st, rows, xk, uk, track_id[b], nknots, s_ref, kappa_ref, lin + ((size_t)b * N + k) * LIN_REC, live);
 }
 
 // plant step: x_next = IRK x M over dt, four lanes per instance; model -1 / -2: the kin / dyn switch of python/main.py:482-489
@@ -362,24 +100,8 @@ __global__ __launch_bounds__(64) void k_rollout_irk(int B, int N, int M, int j_b
     double al = 1.0;
     for (int jj = 0; jj < j; jj++) al *= alpha_red;          // the very products the line search forms
     const size_t ex = ((size_t)b * (N + 1) + k) * 8, eu = ((size_t)b * N + k) * 2;
-    double xs[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) xs[i] = xp[ex + i] + al * (x[ex + i] - xp[ex + i]);
-    const double u_T = up[eu] + al * (u[eu] - up[eu]), u_d = up[eu + 1] + al * (u[eu + 1] - up[eu + 1]);
-    const int tid = track_id[b];
-    TrackSeg trk;
-    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, xs[0]);
     IRK_ROWS(rows, tab, st)
-    const double hb = rows.hb;
-    for (int m = 0; m < M; m++) {
-        double K[8], J[8][10];
-        irk_step<MODEL, false>(st, rows, xs, u_T, u_d, trk, K, J);
-#pragma unroll
-        for (int i = 0; i < 8; i++) xs[i] += quad_sum(hb * K[i]);
-    }
-    if (q < total && st == 0)
-#pragma unroll
-        for (int i = 0; i < 8; i++) phi[(size_t)pr * 8 + i] = xs[i];
+    irk_rollout_quad<MODEL>(st, rows, M, al, x + ex, xp + ex, u + eu, up + eu, track_id[b], nknots, s_ref, kappa_ref, phi + (size_t)pr * 8, q < total);
 }
 
 // host: tableau + the constant actuator blocks (I + h/t A)^-1 for the step size h
@@ -449,6 +171,15 @@ void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int j_begin, int j_end, double *
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6) LAUNCH_RO(IHM2MPC_MODEL_FDYN6);
     else LAUNCH_RO(IHM2MPC_MODEL_FKIN6);
 #undef LAUNCH_RO
+}
+
+int ihm2_upload_irk_tab(ihm2mpc_handle *h)
+{
+    if (h->cfg.integrator_type == IHM2MPC_INTEG_ERK) return 0;
+    const IrkTab tab = make_tab(h->cfg.integrator_type, h->cfg.dt / h->cfg.M);
+    if (!h->irk_tab && hipMalloc(&h->irk_tab, sizeof(IrkTab)) != hipSuccess) return 1;
+    if (hipMemcpyAsync(h->irk_tab, &tab, sizeof(IrkTab), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+    return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 1;
 }
 
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)

@@ -237,8 +237,9 @@ void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, c
     const int blocks = (h->B + 63) / 64;
     // the plain kinematic plant shares the integrator of the shooting intervals (bit-identical to lane N of the persistent loop); for
     // the few instances of a real-time controller (the batches that also take the column-parallel linearisation) its discarded
-    // sensitivities would put 0.1 ms on the critical path of ihm2mpc_step: those take the state-only rollout
-    if (model == IHM2MPC_MODEL_FKIN6 && (long)h->B * h->N > 128)
+    // sensitivities would put 0.1 ms on the critical path of ihm2mpc_step: those take the state-only rollout, and so does a handle whose
+    // shooting intervals use the collocation integrator (nothing to share: the loop runs the plant as a phase of its own on one lane)
+    if (model == IHM2MPC_MODEL_FKIN6 && (long)h->B * h->N > 128 && h->cfg.integrator_type == IHM2MPC_INTEG_ERK)
         hipLaunchKernelGGL(k_sim_step_kin, dim3(blocks), dim3(64), 0, stream, h->B, M_sim, h->cfg.dt, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id,
                            x, u, xn, active, h->lin + (size_t)h->B * h->N * LIN_REC);
     else

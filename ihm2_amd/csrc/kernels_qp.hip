@@ -34,6 +34,7 @@
 #include "ihm2mpc_internal.h"
 #include "device_steps.hpp"
 #include "sqp_body.hpp"
+#include "irk_body.hpp"
 #include "riccati_mfma.hpp"
 
 using namespace ihm2;
@@ -870,6 +871,15 @@ __device__ __noinline__ void call_integrate_fkin6(const double *xk, const double
 {
     dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xk, uk, x_next, tid, M, dt, nknots, s_ref, kappa_ref, rec, xn_out, nullptr);
 }
+// the collocation integrator in the loop: the wave's 16 quads take the intervals base .. base + 15 (kernels_irk.hip: four lanes per interval)
+__device__ __noinline__ void call_linearize_irk_fkin6(const IrkTab *tab, int b, int base, int N, int nknots, const double *s_ref, const double *kappa_ref, int tid,
+                                                      const double *x, const double *u, double *lin)
+{
+    const int st = threadIdx.x & 3, q = base + ((int)threadIdx.x >> 2), k = min(q, N - 1);
+    const IrkRows rows = irk_rows_from(tab, st);
+    irk_linearize_quad<IHM2MPC_MODEL_FKIN6>(st, rows, x + ((size_t)b * (N + 1) + k) * 8, u + ((size_t)b * N + k) * 2, tid, nknots, s_ref, kappa_ref,
+                                            lin + ((size_t)b * N + k) * LIN_REC, q < N);
+}
 __device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
                                            const int32_t *track_id, const double *xs, const double *us, double *xn)
 {
@@ -881,6 +891,11 @@ __device__ __noinline__ void call_line_search_fkin6(const LsArgs &ls, int b, int
     line_search_body<IHM2MPC_MODEL_FKIN6>(ls, b, it, last);
 }
 
+__device__ __noinline__ void call_line_search_fkin6_irk(const LsArgs &ls, int b, int it, int last)
+{
+    line_search_body<IHM2MPC_MODEL_FKIN6, true>(ls, b, it, last);
+}
+
 struct StepArgs {
     int n_steps, model, M_sim, M, nknots, lap_wrap, freeze;
     int sqp_iters;                          // 0: one RTI iteration per step; > 0: SQP mode, that many iterations with the line search
@@ -890,11 +905,15 @@ struct StepArgs {
     int32_t *active;                        // (B) or nullptr = all active
     double *hist_u0, *hist_x0;              // (n_steps,B,2), (n_steps,B,8) or nullptr
     int32_t *hist_st, *hist_it;             // (n_steps,B) or nullptr
+    const IrkTab *irk_tab;                  // IRK = 1: the tableau of the shooting intervals' collocation step, in device memory
 };
 
 // SQP = 0: one RTI iteration per step (the SQP code is compiled out: next to the QP body it changed the register allocation of
 // the whole kernel and tripled the step time); SQP = 1: sqp_iters iterations with the KKT test and the line search.
-template <int NSLOT, int NSOFT, int PATH, int UNI, int SQP>
+// IRK = 1: the shooting intervals are integrated by the collocation step of kernels_irk.hip (three passes of 16 quads); the kinematic plant
+// stays RK4 x M_sim and takes a phase of its own on lane 0 like the dynamic plants (the state-only rollout: it no longer rides along
+// with the interval lanes).
+template <int NSLOT, int NSOFT, int PATH, int UNI, int SQP, int IRK = 0>
 __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, const LsArgs *lsp)
 {
     // the loop's own arguments are read from device memory where they are used: as by-value kernel arguments they stayed in
@@ -928,7 +947,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
         const double x_old = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
         // The kinematic plant (model 0) is one more "interval" of the linearisation -- lane N integrates (x0, u0) with the
         // code of the interval lanes, in lockstep with them -- so it costs no time; the dynamic plants take a phase of their own.
-        const bool kin_plant = s.model == IHM2MPC_MODEL_FKIN6;
+        const bool kin_plant = !IRK && s.model == IHM2MPC_MODEL_FKIN6;
         double *spare = s.lin + (size_t)B * N * LIN_REC;
         if (!kin_plant && act) {
             if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
@@ -954,6 +973,10 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             {
                 const int tid = a.track_id[b];
                 const bool with_plant = kin_plant && it == 0 && act;
+                if (IRK) {
+                    for (int base = 0; base < N; base += 16)
+                        call_linearize_irk_fkin6(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                } else
                 for (int k = lane; k < N + (with_plant ? 1 : 0); k += 64) {
                     const bool plant = k == N;
                     const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
@@ -979,7 +1002,8 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm);
             __syncthreads();
             if (SQP) {
-                call_line_search_fkin6(ls, b, it, it == n_it - 1);
+                if (IRK) call_line_search_fkin6_irk(ls, b, it, it == n_it - 1);
+                else call_line_search_fkin6(ls, b, it, it == n_it - 1);
                 __syncthreads();
             }
         }
@@ -1040,11 +1064,14 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
 #endif
 {
     if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return 1;
-    if (h->cfg.integrator_type != IHM2MPC_INTEG_ERK || h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK) return 1;      // the loop integrates with RK4
+    if (h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK) return 1;      // the loop's plant integrates with RK4
+    const bool irk = h->cfg.integrator_type != IHM2MPC_INTEG_ERK;       // collocation step on the shooting intervals: all-hard, batch-shared tables only
+    if (irk && !(h->irk_tab && h->uniform_H && h->uniform_CD && (h->cfg.nlp_solver_type != IHM2MPC_SQP || !h->sqp_globalization || h->ls_phi))) return 1;
     const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
     if (sqp && !h->ls_x) return 1;        // the caller allocates the line-search buffers first
     const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8;
 #if QP_SET == 0
+    if (!hard && irk) return 1;
     if (!hard) return ihm2_launch_steps_soft(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
 #else
     if (hard) return 1;
@@ -1060,6 +1087,7 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     s.x0 = h->x0; s.yref = h->yref; s.yref_e = h->yref_e; s.lin = h->lin;
     s.active = (freeze || h->active_set) ? h->active : nullptr;
     s.hist_u0 = hist_u0; s.hist_x0 = hist_x0; s.hist_st = hist_st; s.hist_it = hist_it;
+    s.irk_tab = (const IrkTab *)h->irk_tab;
     // every field of s is set: upload it (and the line search's block in the SQP mode)
     static_assert(sizeof(StepArgs) <= 32 * sizeof(double), "step_args holds 256 bytes");
     static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
@@ -1071,7 +1099,8 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     std::memcpy(stage, &s, sizeof(StepArgs));
     if (hipMemcpyAsync(h->step_args, stage, sizeof(StepArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
     if (sqp) {
-        const LsArgs ls_host = make_ls_args(h);
+        LsArgs ls_host = make_ls_args(h);
+        if (irk) ls_host.phase = 3;        // the trial points' collocation rollouts are done in the loop, one step length at a time
         std::memcpy(stage + 512, &ls_host, sizeof(LsArgs));
         if (hipMemcpyAsync(h->ls_args, stage + 512, sizeof(LsArgs), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
     }
@@ -1085,6 +1114,17 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
         hipLaunchKernelGGL((k_steps<NS_, NO_, PT_, UN_, SQ_>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                      \
     } while (0)
 #if QP_SET == 0
+#define LAUNCH_STEPS_IRK(NS_, SQ_)                                                                                                     \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute((const void *)k_steps<NS_, 0, 0, 1, SQ_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipLaunchKernelGGL((k_steps<NS_, 0, 0, 1, SQ_, 1>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                         \
+    } while (0)
+    if (irk) {
+        if (h->nslot_lane <= 5) { if (sqp) LAUNCH_STEPS_IRK(5, 1); else LAUNCH_STEPS_IRK(5, 0); }
+        else { if (sqp) LAUNCH_STEPS_IRK(8, 1); else LAUNCH_STEPS_IRK(8, 0); }
+        return 0;
+    }
+#undef LAUNCH_STEPS_IRK
 #define LAUNCH_STEPS(NS_, UN_) do { if (sqp) LAUNCH_STEPS_1(NS_, 0, 0, UN_, 1); else LAUNCH_STEPS_1(NS_, 0, 0, UN_, 0); } while (0)
     if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 1); else LAUNCH_STEPS(5, 0); }
     else { if (uni) LAUNCH_STEPS(8, 1); else LAUNCH_STEPS(8, 0); }

@@ -4,6 +4,7 @@
 
 #include "ihm2mpc_internal.h"
 #include "model.hpp"
+#include "irk_body.hpp"
 
 namespace ihm2 {
 
@@ -29,9 +30,10 @@ struct LsArgs {
     int n_alpha;
     // the ladder in two launches (IRK): phase 1 tries the first j_limit step lengths and marks the instances that need more in
     // `pending` without touching their iterate; phase 2 redoes the ladder of exactly those (same arithmetic, all rollouts present);
-    // phase 0: one launch, the whole ladder
+    // phase 0: one launch, the whole ladder; phase 3 (persistent loop): the rollouts are done here, before each trial
     int phase, j_limit;
     int32_t *pending;
+    const IrkTab *irk_tab;
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -68,7 +70,8 @@ __device__ __forceinline__ void rollout(double (&x)[8], double u_T, double u_d, 
 
 // The convergence test + line search of instance b, run by the calling wavefront (lane = threadIdx.x).  it: SQP iteration index
 // of this solve, last: it == max_iter - 1.  Called by k_line_search (one launch per iteration) and by the persistent loop.
-template <int MODEL>
+// ROLL: the collocation rollouts of the trial points are done here, one step length at a time (persistent loop with IRK; LsArgs.phase = 3)
+template <int MODEL, bool ROLL = false>
 __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, const int it, const int last)
 {
     const int lane = threadIdx.x;
@@ -277,6 +280,17 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
             if (lane == 0) a.pending[b] = 1;
             return;
         }
+        if (ROLL) {         // collocation rollouts of this trial point: the wave's 16 quads over the intervals, then all lanes see them
+            const int st = lane & 3;
+            const IrkRows rows = irk_rows_from(a.irk_tab, st);
+            for (int base = 0; base < N; base += 16) {
+                const int q = base + (lane >> 2), k = min(q, N - 1);
+                const size_t ex = ((size_t)b * NS + k) * 8, eu = ((size_t)b * N + k) * 2;
+                irk_rollout_quad<MODEL>(st, rows, a.M, al, a.x + ex, a.xp + ex, a.u + eu, a.up + eu, tid, a.nknots, a.s_ref, a.kappa_ref,
+                                        const_cast<double *>(a.phi) + (((size_t)jtrial * a.B + b) * N + k) * 8, q < N);
+            }
+            __syncthreads();
+        }
         double c1, i1;
         merit(al, jtrial, false, c1, i1);
         const double m1 = c1 + i1;
@@ -321,7 +335,7 @@ static inline LsArgs make_ls_args(ihm2mpc_handle *h)
     a.done = h->ls_done; a.sqp_status = h->ls_status; a.sqp_iter = h->ls_iter; a.qp_acc = h->ls_qp_acc;
     a.alpha = h->ls_alpha; a.u0 = h->u0;
     a.phi = (h->cfg.integrator_type != IHM2MPC_INTEG_ERK) ? h->ls_phi : nullptr; a.n_alpha = h->ls_nalpha;
-    a.phase = 0; a.j_limit = 0; a.pending = h->ls_pending;
+    a.phase = 0; a.j_limit = 0; a.pending = h->ls_pending; a.irk_tab = (const IrkTab *)h->irk_tab;
     return a;
 }
 

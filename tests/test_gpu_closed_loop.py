@@ -159,9 +159,11 @@ def test_closed_loop_with_the_live_solver_options(track):
 
 
 LIVE = dict(nlp_solver_type="SQP", nlp_solver_max_iter=2, globalization="MERIT_BACKTRACKING")       # python/main.py:230-237
+IRK = dict(integrator_type="IRK", sim_method_num_steps=1)                                              # python/main.py:234-236
 
 
-@pytest.mark.parametrize("plant,n_max,B,opts", [(0, 2.0, 150, {}), (-1, 0.9, 150, {}), (0, 2.0, 1100, {}), (0, 2.0, 150, LIVE), (-1, 2.0, 70, LIVE)])
+@pytest.mark.parametrize("plant,n_max,B,opts", [(0, 2.0, 150, {}), (-1, 0.9, 150, {}), (0, 2.0, 1100, {}), (0, 2.0, 150, LIVE), (-1, 2.0, 70, LIVE),
+                                                (0, 2.0, 150, IRK), (-1, 0.9, 70, IRK), (0, 2.0, 150, {**LIVE, **IRK}), (-1, 2.0, 70, {**LIVE, **IRK})])
 def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts, monkeypatch):
     """ihm2mpc_run_steps (every instance runs its control steps back to back on its own wavefront, one launch) gives the
     results of the same number of ihm2mpc_step calls: same device functions, same order per instance.  B = 1100 does not fit
@@ -188,10 +190,11 @@ def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts, monke
                 s.step(40.0, model=plant, M_sim=30)
                 h["u0"].append(s.get_u0()); h["x0"].append(s.get_x0()); h["status"].append(s.get_status()); h["qp_iter"].append(s.get_qp_iter())
             h = {k: np.array(v) for k, v in h.items()}
-        res.append((h, s.get_x(), s.get_u(), s.get_multipliers(), s.get_sqp_stats() if opts else None))
+        res.append((h, s.get_x(), s.get_u(), s.get_multipliers(), s.get_sqp_stats() if "nlp_solver_type" in opts else None))
         s.free()
     (ha, xa, ua, ma, sa), (hb, xb, ub, mb, sb) = res
-    if opts:
+    sqp = "nlp_solver_type" in opts
+    if sqp:
         np.testing.assert_array_equal(sa["sqp_iter"], sb["sqp_iter"]); np.testing.assert_array_equal(sa["alpha"], sb["alpha"])
     np.testing.assert_array_equal(ha["status"], hb["status"])
     np.testing.assert_array_equal(ha["qp_iter"], hb["qp_iter"])
@@ -199,7 +202,7 @@ def test_persistent_loop_equals_step_by_step(track, plant, n_max, B, opts, monke
     np.testing.assert_array_equal(ha["u0"], hb["u0"])
     np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
     np.testing.assert_array_equal(ma[0], mb[0]); np.testing.assert_array_equal(ma[1], mb[1])
-    if opts:        # SQP mode: the step lengths and iteration counts of the last solve agree as well
+    if sqp:         # SQP mode: the step lengths and iteration counts of the last solve agree as well
         assert np.isin(ha["status"], (0, 2)).mean() > (0.9 if plant == 0 else 0.8)
     else:
         assert (ha["status"] == 0).mean() > (0.9 if plant == 0 else 0.7)      # n_max 0.9 with the dynamic plant: some QPs are infeasible
