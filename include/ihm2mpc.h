@@ -75,8 +75,8 @@ extern "C" {
  * collocation x M steps, 3 Newton iterations per step from K = 0 with a fresh Jacobian each (acados' defaults), forward
  * sensitivities by the implicit-function theorem; GL4 = GAUSS_LEGENDRE (acados' default, python/main.py:234-236), RADAU4 =
  * GAUSS_RADAU_IIA (python/main.py:395-400, python/sim.py:28-33).  Both NLP solver types run on either integrator (the live options of
- * python/main.py:227-238 are SQP + MERIT_BACKTRACKING + IRK); the persistent loop (ihm2mpc_run_steps in one launch) is RK4 only and
- * falls back to launches per step otherwise. */
+ * python/main.py:227-238 are SQP + MERIT_BACKTRACKING + IRK); the persistent loop (ihm2mpc_run_steps in one launch) takes RK4 or IRK on the
+ * shooting intervals (all-hard, batch-shared tables for IRK) with an RK4 plant, and falls back to launches per step otherwise. */
 #define IHM2MPC_INTEG_ERK 0
 #define IHM2MPC_INTEG_IRK_GL4 1
 #define IHM2MPC_INTEG_IRK_RADAU4 2

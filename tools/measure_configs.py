@@ -139,6 +139,10 @@ if __name__ == "__main__":
                    # the live options as a whole (python/main.py:227-238): SQP x 2, MERIT_BACKTRACKING, IRK
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", integrator="IRK")),
                    (rti_throughput, dict(model="fkin6", B=8192, sqp="MERIT_BACKTRACKING", integrator="IRK")),
+                   # the same in the persistent loop (IRK inside k_steps)
+                   (rti_throughput, dict(model="fkin6", B=1024, integrator="IRK", persistent=True, steps=500, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", integrator="IRK", persistent=True, steps=500, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="FIXED_STEP", integrator="IRK", persistent=True, steps=500, warmup=20)),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0))),
                    (closed_loop_config5, dict(B=4096, steps=200, device_loop=True)),
