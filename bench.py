@@ -100,11 +100,7 @@ def cpu_baseline(ocp, track, x0_all, budget_s=12.0, gpu_state=None, device=0):
     threads = int(os.environ.get("IHM2_CPU_THREADS", min(orc.num_threads(), len(os.sched_getaffinity(0)), 16)))
     Bs = min(512, x0_all.shape[0])
     x0 = x0_all[:Bs].copy()
-    x = np.zeros((Bs, N_H + 1, 8)); u = np.zeros((Bs, N_H, 2)); x[:, 0] = x0
-    for k in range(N_H):      # held-input rollout as a cheap initial guess
-        u[:, k] = x0[:, 6:8]
-        x[:, k + 1] = P.sim_step(x[:, k], u[:, k], 0, M_SUB, nthreads=threads)
-    x[:, :, 1] = np.clip(x[:, :, 1], -1.5, 1.5)
+    x, u = orc.stanley_guess(P, track.s_ref, track.kappa_ref, x0, N_H, M_SUB)      # the warm start the GPU run takes (ihm2mpc_init_guess)
     pi = lam = None
     xcur = x0
     solves, t_acc, steps = 0, 0.0, 0

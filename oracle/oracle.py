@@ -286,6 +286,23 @@ class OracleProblem:
         return xn
 
 
+def stanley_guess(P, s_ref, kappa_ref, x0, N, M=25, l_R=0.7853):
+    """Initial prediction for a batch that starts anywhere on the track: rollout of the model from x0 under Stanley-type feedback
+    (StanleyController.compute_control, python/main.py:139-163; torque: P-term on the speed only), inputs clipped to the box and the
+    steering-rate row -- the CPU counterpart of ihm2mpc_init_guess (kernels_misc.hip::k_init_guess) for the reference's bounds."""
+    B = x0.shape[0]
+    x = np.zeros((B, N + 1, 8)); u = np.zeros((B, N, 2)); x[:, 0] = x0
+    for k in range(N):
+        xk = x[:, k]
+        kap = np.interp(xk[:, 0], s_ref, kappa_ref)
+        uT = np.clip(90.0 * (x0[:, 3] - xk[:, 3]), -500, 500)
+        ud = np.arctan(2 * np.tan(np.arcsin(np.clip(kap * l_R, -0.9, 0.9)))) - 1.8 * xk[:, 2] - np.arctan(5.5 * xk[:, 1] / (2 + xk[:, 3]))
+        ud = np.clip(np.clip(ud, xk[:, 7] - 0.02, xk[:, 7] + 0.02), -0.5, 0.5)
+        u[:, k] = np.stack([uT, ud], 1)
+        x[:, k + 1] = P.sim_step(xk, u[:, k], 0, M)
+    return x, u
+
+
 def prepare_step(N, x0, s_target, x, u):
     """Shift + reference ramp in place on x (B,N+1,8), u (B,N,2); returns yref (B,N,12), yref_e (B,8)."""
     B = x.shape[0]

@@ -9,19 +9,7 @@ N = 40
 
 
 def _stanley_guess(P, track, x0, M=25):
-    from ihm2_amd.constants import l_R
-
-    B = x0.shape[0]
-    x = np.zeros((B, N + 1, 8)); u = np.zeros((B, N, 2)); x[:, 0] = x0
-    for k in range(N):
-        xk = x[:, k]
-        kap = np.interp(xk[:, 0], track.s_ref, track.kappa_ref)
-        uT = np.clip(90.0 * (x0[:, 3] - xk[:, 3]), -500, 500)
-        ud = np.arctan(2 * np.tan(np.arcsin(np.clip(kap * l_R, -0.9, 0.9)))) - 1.8 * xk[:, 2] - np.arctan(5.5 * xk[:, 1] / (2 + xk[:, 3]))
-        ud = np.clip(np.clip(ud, xk[:, 7] - 0.02, xk[:, 7] + 0.02), -0.5, 0.5)
-        u[:, k] = np.stack([uT, ud], 1)
-        x[:, k + 1] = P.sim_step(xk, u[:, k], 0, M)
-    return x, u
+    return orc.stanley_guess(P, track.s_ref, track.kappa_ref, x0, N, M)
 
 
 def test_sqp_iterations_reach_kkt_points(track):
