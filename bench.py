@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 2],
                     help="BASELINE.json configs[.]: 1 = batch 1024 kinematic (the metric's configuration); 2 = batch 8192 dynamic bicycle with "
                          "soft nonlinear track rows, reported as written (fdyn6) and with un-crossed slip angles (fdyn6u)")
+    ap.add_argument("--live-options", action="store_true",
+                    help="configs[1]'s workload with the solver options the reference runs live (python/main.py:227-238: SQP x 2 iterations, "
+                         "MERIT_BACKTRACKING, IRK with 4 Gauss-Legendre stages and 1 step) instead of the metric's SQP_RTI + RK4 x 25; one GPU")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N>1 path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
@@ -148,6 +151,8 @@ def main():
         _lib.LIB_PATH = os.path.abspath(args.lib)
     if args.config == 2:
         return main_config2(args)
+    if args.live_options:
+        return main_live_options(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -421,6 +426,29 @@ def main_config2(args):
         "note": "value = the model as written; its QPs are mostly infeasible (open-loop unstable, DESIGN.md section 2). variants.fdyn6u = "
                 "un-crossed slip angles (named deviation), stage terminal box, re-initialisation of failed instances; variants.fdyn6u_irk = the same "
                 "with the reference's live integrator (python/main.py:234-236: IRK, 4 Gauss-Legendre stages, 1 step) instead of RK4 x 25"}))
+
+
+def main_live_options(args):
+    """configs[1]'s batch with the reference's live solver options (python/main.py:227-238) instead of the metric's SQP_RTI + RK4: SQP with
+    two iterations, merit backtracking and the 4-stage Gauss-Legendre collocation step -- all control steps in one launch (IRK and the line
+    search inside the persistent loop) unless --per-step-launches."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from measure_configs import rti_throughput
+
+    B = args.batch
+    r = rti_throughput(model="fkin6", B=B, steps=args.steps, warmup=args.warmup, sqp="MERIT_BACKTRACKING", integrator="IRK", persistent=not args.per_step_launches)
+    print(json.dumps({
+        "metric": "NMPC control steps/s (batch), live solver options: SQP x 2, MERIT_BACKTRACKING, IRK GL4 x 1, N=40, nx=8, fkin6",
+        "value": r["solves_per_s"], "unit": "control steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[1] with the live options of python/main.py:227-238: batch={B} kinematic bicycle fkin6, N=40, dt=0.05, SQP max_iter 2, "
+                               "MERIT_BACKTRACKING, IRK (4 Gauss-Legendre stages, 1 step per interval), RK4 x 25 plant, track fsds_competition_1; "
+                               + ("launches per phase and step" if args.per_step_launches else "all steps in one launch (ihm2mpc_run_steps)"),
+                   "batch_per_gpu": B, "N": N_H},
+        "success_fraction": r["ok_fraction"], "status_counts": r["status"], "qp_iter_mean_per_step": r["qp_iter_mean"],
+        "sqp_iter_mean": r.get("sqp_iter_mean"), "alpha_mean": r.get("alpha_mean"), "alpha_lt1": r.get("alpha_lt1"),
+        "note": "status 2 = ACADOS_MAXITER after the two iterations, which the reference accepts (python/main.py:326); not the headline metric "
+                "(that is the default run: SQP_RTI, RK4 x 25)"}))
 
 
 if __name__ == "__main__":
