@@ -672,7 +672,8 @@ static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
             if (sqp_phi_buffer(h, &n_alpha)) return -1;
             // most instances accept one of the first step lengths: those rollouts for everybody, the rest of the ladder only for the
             // instances the first line-search launch leaves open (which then redo their ladder: same arithmetic as one launch)
-            const int j_first = n_alpha < 3 ? n_alpha : 3;
+            // (a few instances -- the whole ladder is one round of wavefronts on the chip -- keep the single launch: two launches less per iteration)
+            const int j_first = (n_alpha < 3 || (long)n_alpha * (long)B * (long)N <= 16384) ? n_alpha : 3;
             ihm2_launch_rollout_irk(h, 0, j_first, h->ls_phi, nullptr);
             if (j_first < n_alpha) {
                 ihm2_launch_line_search(h, it, it == n_iter - 1, 1, j_first);
