@@ -651,17 +651,13 @@ static int sqp_phi_buffer(ihm2mpc_handle *h, int *n_alpha_out)
 static int sqp_iterations(ihm2mpc_handle *h, int n_iter, bool join)
 {
     if (sqp_buffers(h)) return -1;
-    const size_t B = h->B, N = h->N, NS = h->NS;
+    const size_t B = h->B, N = h->N;
     HIP_TRY(hipMemsetAsync(h->ls_done, 0, B * sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->ls_iter, 0, B * sizeof(int32_t), h->stream));
     HIP_TRY(hipMemsetAsync(h->ls_qp_acc, 0, B * sizeof(int32_t), h->stream));
     for (int it = 0; it < n_iter; it++) {
         // the iterate the QP is built at: the line search walks from it towards the QP's full step
-        HIP_TRY(hipMemcpyAsync(h->ls_x, h->x, B * NS * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->ls_u, h->u, B * N * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->ls_pi, h->pi, B * NS * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->ls_lam, h->lam, B * NS * NLAM * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->ls_slk, h->slk, B * NS * NLAM * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        ihm2_launch_copy_iterate(h);
         ihm2_launch_linearize(h);
         if (it == 0 && join) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         if (it == n_iter - 1) HIP_TRY(hipEventRecord(h->ev[1], h->stream));

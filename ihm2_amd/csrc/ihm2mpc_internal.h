@@ -138,6 +138,7 @@ int ihm2_upload_irk_tab(ihm2mpc_handle *h);      // (re)builds h->irk_tab for th
 void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int j_begin, int j_end, double *phi, const int32_t *pending);
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,
                          const int32_t *active);
+void ihm2_launch_copy_iterate(ihm2mpc_handle *h);   // x, u, pi, lam, slk -> ls_x, ls_u, ls_pi, ls_lam, ls_slk
 void ihm2_launch_line_search(ihm2mpc_handle *h, int it, int last, int phase = 0, int j_limit = 0);
 int ihm2_launch_qp(ihm2mpc_handle *h);
 // the persistent per-instance loop (kernels_qp.hip); returns 1 if the configuration has no instantiation of it

@@ -29,7 +29,30 @@ __global__ __launch_bounds__(64) void k_line_search(LsArgs a, int it, int last)
     line_search_body<MODEL>(a, blockIdx.x, it, last);
 }
 
+// the iterate the QP is built at, set aside for the line search: five arrays in one launch
+__global__ __launch_bounds__(256) void k_copy_iterate(size_t n8, size_t n2, size_t nl, const double *__restrict__ x, const double *__restrict__ u,
+                                                      const double *__restrict__ pi, const double *__restrict__ lam, const double *__restrict__ slk,
+                                                      double *__restrict__ xp, double *__restrict__ up, double *__restrict__ pip, double *__restrict__ lamp,
+                                                      double *__restrict__ slkp)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nl; e += stride) {
+        lamp[e] = lam[e]; slkp[e] = slk[e];
+        if (e < n8) { xp[e] = x[e]; pip[e] = pi[e]; }
+        if (e < n2) up[e] = u[e];
+    }
+}
+
 }  // namespace
+
+void ihm2_launch_copy_iterate(ihm2mpc_handle *h)
+{
+    const size_t B = h->B, N = h->N, NS = h->NS;
+    const size_t nl = B * NS * NLAM;          // the longest of the five
+    const int blocks = (int)((nl + 255) / 256 < 4096 ? (nl + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_copy_iterate, dim3(blocks), dim3(256), 0, h->stream, B * NS * 8, B * N * 2, nl, h->x, h->u, h->pi, h->lam, h->slk, h->ls_x, h->ls_u, h->ls_pi,
+                       h->ls_lam, h->ls_slk);
+}
 
 // it: SQP iteration index of this solve (0 resets the per-solve counters on the host side), last: it == max_iter - 1;
 // phase / j_limit: LsArgs (the ladder in two launches for the collocation integrator)
