@@ -169,8 +169,10 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
 // count per lane of THAT table), reductions go wave -> LDS -> block, hand-offs are s_barriers; the three sequential sweeps run on
 // wave 0 while the others wait.  NW == 1 compiles to exactly the single-wave code (tid == lane, BSYNC == WSYNC).
 template <int NSLOT, int NSOFT, int PATH, int UNI, int NW = 1>
-__device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, double *sm)
+__device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, double *sm, const bool want_res = true)
 {
+    // want_res = false (wave-uniform): the stationarity residual of the incoming iterate -- an output only (ihm2mpc_get_residuals), a third of
+    // the QP set-up -- is skipped; the persistent RTI loop asks for it on its last step alone
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #define BSYNC() do { if (NW == 1) WSYNC(); else __syncthreads(); } while (0)
@@ -292,6 +294,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         const bool counted = !((k == 0 && j < 8) || (k == N && j >= 8));
         if (j < 8 || k < N) sg = fmax(sg, fabs(acc));
         // stationarity: g + AB' pi_{k+1} - [pi_k;0] - R'(lam_l - lam_u)
+        if (!want_res) continue;
         double st = acc;
         if (k < N) {
             const double *rec = linb + (size_t)k * LIN_REC;
@@ -363,12 +366,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             bool soft = false;
             if (r < NSOFT) { so_zw[r < NSOFT ? r : 0] = a.slot_zw[s]; so_Zw[r < NSOFT ? r : 0] = a.slot_Zw[s]; soft = a.slot_Zw[s] >= 0.0; }
             // soft sides may be violated: they do not count as infeasibility of the iterate
-            if (fin(lb)) { s_dl[r] = lb - cz; if (!soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + c] * s_dl[r])); } }
-            if (fin(ubd)) { s_du[r] = ubd - cz; if (!soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + 14 + c] * s_du[r])); } }
+            if (fin(lb)) { s_dl[r] = lb - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + c] * s_dl[r])); } }
+            if (fin(ubd)) { s_du[r] = ubd - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + 14 + c] * s_du[r])); } }
         }
     }
-    r_stat = blk_max(r_stat); r_eq = blk_max(r_eq); r_ineq = blk_max(r_ineq); r_comp = blk_max(r_comp);
-    if (tid == 0) {
+    if (want_res) { r_stat = blk_max(r_stat); r_eq = blk_max(r_eq); r_ineq = blk_max(r_ineq); r_comp = blk_max(r_comp); }
+    if (want_res && tid == 0) {
         double *rs = a.res + (size_t)b * 4;
         rs[0] = r_stat; rs[1] = r_eq; rs[2] = r_ineq; rs[3] = r_comp;
     }
@@ -999,7 +1002,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
                 dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
                 __syncthreads();
             }
-            qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm);
+            qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm, SQP || step + 1 == s.n_steps);
             __syncthreads();
             if (SQP) {
                 if (IRK) call_line_search_fkin6_irk(ls, b, it, it == n_it - 1);
