@@ -264,7 +264,10 @@ int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps);
  * plant state (:503-504) stops the car where it is, s > lap_stop ends its run (:514-517); the plant mask of
  * ihm2mpc_set_active is updated accordingly and kept across calls until ihm2mpc_set_active(NULL).  freeze == 0: a car masked
  * by ihm2mpc_set_active keeps solving, only its plant stands still (as in ihm2mpc_step).  Histories (any may be NULL): u0 (n_steps,B,2), x0 after the plant
- * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block). */
+ * (n_steps,B,8), status and QP iterations (n_steps,B); copied in stream order (pinned destinations do not block).  ihm2mpc_get_residuals
+ * afterwards: the NLP residuals of the iterate the LAST step started from, as after n_steps calls of ihm2mpc_step (in the RTI mode the
+ * loop does not form them on the steps before -- they are an output, not an input of the iteration; a car that stopped earlier in the
+ * launch keeps what an earlier call left). */
 int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_target, int32_t n_steps, int32_t freeze,
                       double lap_stop, double *u0_hist, double *x0_hist, int32_t *status_hist, int32_t *qp_iter_hist);
 
