@@ -629,11 +629,22 @@ static int sqp_buffers(ihm2mpc_handle *h)
 }
 
 // SQP mode with the collocation integrator: room for the line search's trial-point rollouts (every step length of the ladder)
+// Trial step lengths of the backtracking ladder 1, rho, rho^2, ... >= alpha_min -- the same floating-point sequence as the loop of
+// line_search_body (sqp_body.hpp).  ihm2mpc_set_sqp_options refuses option pairs whose ladder is longer than IHM2MPC_LS_MAX_TRIALS:
+// one length everywhere (the buffer of the collocation rollouts, the rollout launches, the line search).
+#define IHM2MPC_LS_MAX_TRIALS 64
+static int ladder_length(double alpha_min, double alpha_red)
+{
+    int n = 1;
+    for (double al = alpha_red; al >= alpha_min && n <= IHM2MPC_LS_MAX_TRIALS; al *= alpha_red) n++;
+    return n;
+}
+
 static int sqp_phi_buffer(ihm2mpc_handle *h, int *n_alpha_out)
 {
     const size_t B = h->B, N = h->N;
-    int n_alpha = 1;
-    for (double al = h->sqp_alpha_red; al >= h->sqp_alpha_min && n_alpha < 64; al *= h->sqp_alpha_red) n_alpha++;
+    const int n_alpha = ladder_length(h->sqp_alpha_min, h->sqp_alpha_red);
+    if (n_alpha > IHM2MPC_LS_MAX_TRIALS) return fail("backtracking ladder longer than %d trial steps", IHM2MPC_LS_MAX_TRIALS);
     if (!h->ls_phi || h->ls_nalpha < n_alpha) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->ls_phi) (void)hipFree(h->ls_phi);
@@ -714,6 +725,8 @@ int ihm2mpc_set_sqp_options(ihm2mpc_handle *h, int32_t globalization, double alp
     if (!(alpha_min > 0.0 && alpha_min <= 1.0)) return fail("alpha_min must be in (0, 1]");
     if (!(alpha_reduction > 0.0 && alpha_reduction < 1.0)) return fail("alpha_reduction must be in (0, 1)");
     if (!(eps_sufficient_descent >= 0.0 && eps_sufficient_descent < 1.0)) return fail("eps_sufficient_descent must be in [0, 1)");
+    if (globalization == IHM2MPC_MERIT_BACKTRACKING && ladder_length(alpha_min, alpha_reduction) > IHM2MPC_LS_MAX_TRIALS)
+        return fail("alpha_reduction %g with alpha_min %g makes a backtracking ladder of more than %d trial steps", alpha_reduction, alpha_min, IHM2MPC_LS_MAX_TRIALS);
     h->sqp_globalization = globalization; h->sqp_alpha_min = alpha_min; h->sqp_alpha_red = alpha_reduction; h->sqp_eps = eps_sufficient_descent;
     h->sqp_use_suff = use_sufficient_descent ? 1 : 0; h->sqp_full_step_dual = full_step_dual ? 1 : 0;
     if (tol)

@@ -7,7 +7,10 @@
 //     ihm2mpc_comm_allgather_results / ihm2mpc_comm_allreduce_max (the bench's max-over-ranks timing) / ihm2mpc_comm_free.
 // Blocks may differ in size by construction of the block split: they are padded to the largest block for ncclAllGather (payload:
 // 20 bytes per instance) and trimmed on the host.
-#include <rccl/rccl.h>
+// RCCL is loaded on first use (dlopen): a single-GPU user of libihm2mpc.so neither loads librccl.so nor depends on its presence.
+#include <rccl/rccl.h>      // types and prototypes only: the entry points are resolved at run time
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstring>
@@ -18,10 +21,48 @@
 #include "ihm2mpc_internal.h"
 
 extern int ihm2_fail(const char *fmt, ...);
+
+namespace {
+struct RcclApi {
+    decltype(&ncclGetUniqueId) GetUniqueId;
+    decltype(&ncclCommInitRank) CommInitRank;
+    decltype(&ncclCommInitAll) CommInitAll;
+    decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclAllGather) AllGather;
+    decltype(&ncclAllReduce) AllReduce;
+    decltype(&ncclGroupStart) GroupStart;
+    decltype(&ncclGroupEnd) GroupEnd;
+    decltype(&ncclGetErrorString) GetErrorString;
+    bool ok = false;
+};
+RcclApi rccl;
+
+// 0 = the entry points are there; -1 = librccl.so or one of its symbols is missing (reported through ihm2mpc_last_error)
+int rccl_load()
+{
+    if (rccl.ok) return 0;
+    void *lib = nullptr;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return ihm2_fail("RCCL is not available: %s", dlerror());
+#define RCCL_SYM(field, sym)                                                             \
+    rccl.field = reinterpret_cast<decltype(rccl.field)>(dlsym(lib, #sym));                \
+    if (!rccl.field) return ihm2_fail("librccl.so has no symbol %s", #sym)
+    RCCL_SYM(GetUniqueId, ncclGetUniqueId); RCCL_SYM(CommInitRank, ncclCommInitRank); RCCL_SYM(CommInitAll, ncclCommInitAll);
+    RCCL_SYM(CommDestroy, ncclCommDestroy); RCCL_SYM(AllGather, ncclAllGather); RCCL_SYM(AllReduce, ncclAllReduce);
+    RCCL_SYM(GroupStart, ncclGroupStart); RCCL_SYM(GroupEnd, ncclGroupEnd); RCCL_SYM(GetErrorString, ncclGetErrorString);
+#undef RCCL_SYM
+    rccl.ok = true;
+    return 0;
+}
+}  // namespace
+
 #define NCCL_TRY(call)                                                                                            \
     do {                                                                                                          \
         ncclResult_t r_ = (call);                                                                                 \
-        if (r_ != ncclSuccess) return ihm2_fail("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+        if (r_ != ncclSuccess) return ihm2_fail("%s failed: %s (%s:%d)", #call, rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 #define HIPC_TRY(call)                                                                                            \
     do {                                                                                                          \
@@ -31,6 +72,7 @@ extern int ihm2_fail(const char *fmt, ...);
 
 struct ihm2mpc_group {
     int n;
+    std::vector<int> dev;                       // device of every handle (the handles may be freed before the group)
     std::vector<ihm2mpc_handle *> h;
     std::vector<ncclComm_t> comm;
     std::vector<double *> send_u, recv_u;       // per device: (Bmax, 2), (n, Bmax, 2)
@@ -59,9 +101,12 @@ static int alloc_bufs(int n, int Bmax, double **su, double **ru, int32_t **ss, i
 
 extern "C" {
 
+int ihm2mpc_group_free(ihm2mpc_group *g);
+
 int ihm2mpc_group_create(ihm2mpc_handle *const *handles, int32_t n, ihm2mpc_group **out)
 {
     if (!handles || !out || n < 1) return ihm2_fail("null argument or n < 1");
+    if (rccl_load()) return -1;
     std::vector<int> devs(n);
     int Bmax = 0;
     for (int i = 0; i < n; i++) {
@@ -71,13 +116,21 @@ int ihm2mpc_group_create(ihm2mpc_handle *const *handles, int32_t n, ihm2mpc_grou
         Bmax = std::max(Bmax, handles[i]->B);
     }
     ihm2mpc_group *g = new ihm2mpc_group();
-    g->n = n; g->Bmax = Bmax;
+    g->n = n; g->Bmax = Bmax; g->dev = devs;
     g->h.assign(handles, handles + n);
-    g->comm.resize(n); g->send_u.resize(n); g->recv_u.resize(n); g->send_s.resize(n); g->recv_s.resize(n);
-    NCCL_TRY(ncclCommInitAll(g->comm.data(), n, devs.data()));
+    g->comm.assign(n, nullptr); g->send_u.assign(n, nullptr); g->recv_u.assign(n, nullptr); g->send_s.assign(n, nullptr); g->recv_s.assign(n, nullptr);
+    // every failure from here on releases what the group holds so far (ihm2mpc_group_free skips what is still null)
+    ncclResult_t r = rccl.CommInitAll(g->comm.data(), n, devs.data());
+    if (r != ncclSuccess) {
+        g->comm.assign(n, nullptr);
+        (void)ihm2mpc_group_free(g);
+        return ihm2_fail("ncclCommInitAll failed: %s", rccl.GetErrorString(r));
+    }
     for (int i = 0; i < n; i++) {
-        HIPC_TRY(hipSetDevice(devs[i]));
-        if (alloc_bufs(n, Bmax, &g->send_u[i], &g->recv_u[i], &g->send_s[i], &g->recv_s[i])) return -1;
+        if (hipSetDevice(devs[i]) != hipSuccess || alloc_bufs(n, Bmax, &g->send_u[i], &g->recv_u[i], &g->send_s[i], &g->recv_s[i])) {
+            (void)ihm2mpc_group_free(g);
+            return ihm2_fail("device buffers of the gather could not be allocated on device %d", devs[i]);
+        }
     }
     *out = g;
     return 0;
@@ -89,21 +142,21 @@ int ihm2mpc_group_allgather_results(ihm2mpc_group *g, double *u0_all, int32_t *s
     if (!g || !u0_all || !status_all) return ihm2_fail("null argument");
     for (int i = 0; i < g->n; i++) {
         ihm2mpc_handle *h = g->h[i];
-        HIPC_TRY(hipSetDevice(h->cfg.device));
+        HIPC_TRY(hipSetDevice(g->dev[i]));
         HIPC_TRY(hipMemcpyAsync(g->send_u[i], h->u0, (size_t)h->B * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         HIPC_TRY(hipMemcpyAsync(g->send_s[i], h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
     }
-    NCCL_TRY(ncclGroupStart());
+    NCCL_TRY(rccl.GroupStart());
     for (int i = 0; i < g->n; i++) {
-        NCCL_TRY(ncclAllGather(g->send_u[i], g->recv_u[i], (size_t)g->Bmax * 2, ncclDouble, g->comm[i], g->h[i]->stream));
-        NCCL_TRY(ncclAllGather(g->send_s[i], g->recv_s[i], (size_t)g->Bmax, ncclInt32, g->comm[i], g->h[i]->stream));
+        NCCL_TRY(rccl.AllGather(g->send_u[i], g->recv_u[i], (size_t)g->Bmax * 2, ncclDouble, g->comm[i], g->h[i]->stream));
+        NCCL_TRY(rccl.AllGather(g->send_s[i], g->recv_s[i], (size_t)g->Bmax, ncclInt32, g->comm[i], g->h[i]->stream));
     }
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(rccl.GroupEnd());
     for (int i = 0; i < g->n; i++) {
-        HIPC_TRY(hipSetDevice(g->h[i]->cfg.device));
+        HIPC_TRY(hipSetDevice(g->dev[i]));
         HIPC_TRY(hipStreamSynchronize(g->h[i]->stream));
     }
-    HIPC_TRY(hipSetDevice(g->h[0]->cfg.device));
+    HIPC_TRY(hipSetDevice(g->dev[0]));
     size_t off = 0;
     for (int i = 0; i < g->n; i++) {
         const size_t B = g->h[i]->B;
@@ -118,9 +171,9 @@ int ihm2mpc_group_free(ihm2mpc_group *g)
 {
     if (!g) return 0;
     for (int i = 0; i < g->n; i++) {
-        (void)hipSetDevice(g->h[i]->cfg.device);
+        (void)hipSetDevice(g->dev[i]);
         for (void *p : {(void *)g->send_u[i], (void *)g->recv_u[i], (void *)g->send_s[i], (void *)g->recv_s[i]}) if (p) (void)hipFree(p);
-        if (g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+        if (g->comm[i]) (void)rccl.CommDestroy(g->comm[i]);
     }
     delete g;
     return 0;
@@ -130,12 +183,15 @@ int ihm2mpc_group_free(ihm2mpc_group *g)
 int ihm2mpc_comm_unique_id(uint8_t *id128)
 {
     if (!id128) return ihm2_fail("null argument");
+    if (rccl_load()) return -1;
     static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
     ncclUniqueId id;
-    NCCL_TRY(ncclGetUniqueId(&id));
+    NCCL_TRY(rccl.GetUniqueId(&id));
     std::memcpy(id128, &id, sizeof id);
     return 0;
 }
+
+int ihm2mpc_comm_free(ihm2mpc_handle *h);
 
 // sizes (world): instances of every rank's block (this rank's must equal the handle's batch)
 int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint8_t *id128, const int32_t *sizes)
@@ -144,17 +200,26 @@ int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint
     if (world < 1 || rank < 0 || rank >= world) return ihm2_fail("rank %d out of range for world size %d", rank, world);
     if (h->comm) return ihm2_fail("the handle already has a communicator");
     if (sizes[rank] != h->B) return ihm2_fail("sizes[%d] = %d does not match the handle's batch %d", rank, sizes[rank], h->B);
+    if (rccl_load()) return -1;
     HIPC_TRY(hipSetDevice(h->cfg.device));
     ihm2mpc_comm *c = new ihm2mpc_comm();
-    c->world = world; c->rank = rank; c->Bmax = 0;
+    c->world = world; c->rank = rank; c->Bmax = 0; c->comm = nullptr;
+    c->send_u = c->recv_u = c->red = nullptr; c->send_s = c->recv_s = nullptr;
     c->sizes.assign(sizes, sizes + world);
     for (int r = 0; r < world; r++) c->Bmax = std::max(c->Bmax, (int)sizes[r]);
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
-    NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
-    if (alloc_bufs(world, c->Bmax, &c->send_u, &c->recv_u, &c->send_s, &c->recv_s)) return -1;
-    HIPC_TRY(hipMalloc((void **)&c->red, 2 * sizeof(double)));
-    h->comm = c;
+    h->comm = c;        // from here on ihm2mpc_comm_free releases whatever has been set up
+    ncclResult_t r = rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        (void)ihm2mpc_comm_free(h);
+        return ihm2_fail("ncclCommInitRank failed: %s", rccl.GetErrorString(r));
+    }
+    if (alloc_bufs(world, c->Bmax, &c->send_u, &c->recv_u, &c->send_s, &c->recv_s) || hipMalloc((void **)&c->red, 2 * sizeof(double)) != hipSuccess) {
+        (void)ihm2mpc_comm_free(h);
+        return ihm2_fail("device buffers of the gather could not be allocated");
+    }
     return 0;
 }
 
@@ -166,10 +231,10 @@ int ihm2mpc_comm_allgather_results(ihm2mpc_handle *h, double *u0_all, int32_t *s
     HIPC_TRY(hipSetDevice(h->cfg.device));
     HIPC_TRY(hipMemcpyAsync(c->send_u, h->u0, (size_t)h->B * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPC_TRY(hipMemcpyAsync(c->send_s, h->status, (size_t)h->B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-    NCCL_TRY(ncclGroupStart());
-    NCCL_TRY(ncclAllGather(c->send_u, c->recv_u, (size_t)c->Bmax * 2, ncclDouble, c->comm, h->stream));
-    NCCL_TRY(ncclAllGather(c->send_s, c->recv_s, (size_t)c->Bmax, ncclInt32, c->comm, h->stream));
-    NCCL_TRY(ncclGroupEnd());
+    NCCL_TRY(rccl.GroupStart());
+    NCCL_TRY(rccl.AllGather(c->send_u, c->recv_u, (size_t)c->Bmax * 2, ncclDouble, c->comm, h->stream));
+    NCCL_TRY(rccl.AllGather(c->send_s, c->recv_s, (size_t)c->Bmax, ncclInt32, c->comm, h->stream));
+    NCCL_TRY(rccl.GroupEnd());
     HIPC_TRY(hipStreamSynchronize(h->stream));
     size_t off = 0;
     for (int r = 0; r < c->world; r++) {
@@ -188,7 +253,7 @@ int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value)
     ihm2mpc_comm *c = h->comm;
     HIPC_TRY(hipSetDevice(h->cfg.device));
     HIPC_TRY(hipMemcpyAsync(c->red, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    NCCL_TRY(ncclAllReduce(c->red, c->red + 1, 1, ncclDouble, ncclMax, c->comm, h->stream));
+    NCCL_TRY(rccl.AllReduce(c->red, c->red + 1, 1, ncclDouble, ncclMax, c->comm, h->stream));
     HIPC_TRY(hipMemcpyAsync(value, c->red + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPC_TRY(hipStreamSynchronize(h->stream));
     return 0;
@@ -201,7 +266,7 @@ int ihm2mpc_comm_free(ihm2mpc_handle *h)
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
     for (void *p : {(void *)c->send_u, (void *)c->recv_u, (void *)c->send_s, (void *)c->recv_s, (void *)c->red}) if (p) (void)hipFree(p);
-    (void)ncclCommDestroy(c->comm);
+    if (c->comm) (void)rccl.CommDestroy(c->comm);
     delete c;
     h->comm = nullptr;
     return 0;

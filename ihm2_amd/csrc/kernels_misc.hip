@@ -4,6 +4,9 @@
 //    (python/main.py:303-322), fused.
 //  * k_init_guess: rollout of the model from x0 under Stanley-type feedback
 //    (StanleyController.compute_control, python/main.py:139-163; torque: P-term only).
+#include <algorithm>
+#include <cmath>
+
 #include "ihm2mpc_internal.h"
 #include "model.hpp"
 #include "device_steps.hpp"
@@ -114,7 +117,8 @@ void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_fail
     const int32_t *mask = only_failed ? h->status : nullptr;
     // the rollout is an RK4 rollout whatever the OCP's integrator: with IRK (one step per interval) it takes the 25 sub-steps RK4 needs
     // on the actuator lags (a guess: the first linearisation sees its defects against the OCP's own discretisation)
-    const int M_roll = (h->cfg.integrator_type == IHM2MPC_INTEG_ERK) ? h->cfg.M : 25;
+    // (sub-steps of at most 2 ms: RK4 is stable on the 1 ms torque lag up to 2.78 ms -- a longer interval takes more of them)
+    const int M_roll = (h->cfg.integrator_type == IHM2MPC_INTEG_ERK) ? h->cfg.M : std::max(25, (int)std::ceil(h->cfg.dt / 2e-3));
 #define LAUNCH_IG(MD)                                                                                                          \
     hipLaunchKernelGGL(k_init_guess<MD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, M_roll, h->cfg.dt,      \
                        v_ref_scale, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x0, h->lbu, h->ubu, h->lg, h->ug,    \

@@ -1023,10 +1023,9 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
 
 }  // namespace
 
-// This file is compiled TWICE (Makefile): QP_SET = 0 holds the all-hard instantiations (the reference's OCP), built with LLVM's
-// iterative ILP scheduler (-5 %); QP_SET = 1 holds the soft / track-row instantiations, built with the default scheduler:
-// under the ILP scheduler the instantiation <8,3,1,1> returned wrong statuses for some (correct) source variants -- it spills
-// ~1 KB per lane -- while the default scheduler has been right for every variant.
+// This file is compiled TWICE (Makefile) only to halve the build time: QP_SET = 0 holds the all-hard instantiations (the reference's
+// OCP), QP_SET = 1 the soft / track-row instantiations -- same flags, same (default) scheduler.  `make ilp` builds both again under
+// LLVM's iterative ILP scheduler into the test artefact libihm2mpc_ilp.so (tests/test_gpu_configs.py compares the two builds).
 #ifndef QP_SET
 #error "compile with -DQP_SET=0 (all-hard instantiations) or -DQP_SET=1 (soft / track-row instantiations)"
 #endif

@@ -296,7 +296,9 @@ __device__ __forceinline__ void line_search_body(const LsArgs &a, const int b, c
         const double m1 = c1 + i1;
         if (a.use_suff ? (m1 - m0 <= a.eps * al * D) : (m1 < m0)) break;
         al *= a.alpha_red;
-        if (al < a.alpha_min) { al = a.alpha_min; break; }
+        // (the second condition never decides: ihm2mpc_set_sqp_options refuses ladders longer than the rollout buffer; it keeps a
+        // stale option block from reading or writing past phi)
+        if (al < a.alpha_min || (a.phi && jtrial + 1 >= a.n_alpha)) { al = a.alpha_min; break; }
     }
     __syncthreads();
     for (int e = lane; e < NS * 8; e += 64) {

@@ -153,3 +153,159 @@ class DeviceGroup:
 
         if self._g:
             _lib.check(self.lib.ihm2mpc_group_free(self._g)); self._g = C.c_void_p()
+
+
+class RankContext:
+    """The ranks of one job and its three exchanges -- barrier, max over the ranks, final gather of ``(u0, status)`` -- over one of
+
+    * ``"none"``   one rank: nothing to exchange;
+    * ``"rccl"``   the C ABI's own RCCL communicator (:class:`NativeComm`, no PyTorch);
+    * ``"torch"``  ``torch.distributed`` (backend ``nccl`` = RCCL on a GPU node, ``gloo`` to rehearse on one device or on the CPU).
+
+    ``rank`` / ``local_rank`` / ``world`` come from the launcher's environment (``torch.distributed.run`` or :func:`spawn_ranks`).
+    """
+
+    def __init__(self, carrier: str = "auto", backend: str = "nccl", device: int | None = None):
+        import os
+
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = self.local_rank if device is None else int(device)
+        self.addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self.port = int(os.environ.get("MASTER_PORT", "29500"))
+        force = os.environ.get("IHM2_FORCE_DIST") == "1"          # rehearse the exchange path with one rank
+        if self.world == 1 and not force:
+            carrier = "none"
+        elif carrier == "auto":
+            carrier = "torch"
+        self.carrier, self.backend = carrier, backend
+        self.on_gpu = backend == "nccl"
+        self._dist = None
+        self._native = None
+        if carrier == "torch":
+            import torch
+            import torch.distributed as dist
+
+            if self.on_gpu:
+                torch.cuda.set_device(self.device)
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.device))
+            else:
+                dist.init_process_group(backend="gloo")
+            self._dist = dist
+
+    def bounds(self, total: int) -> tuple[int, int]:
+        return shard_bounds(total, self.world, self.rank)
+
+    def attach(self, solver, total: int) -> None:
+        """``solver`` holds this rank's block of ``total`` instances (the RCCL carrier builds its communicator on the handle)."""
+        self.total = int(total)
+        if self.carrier == "rccl":
+            if self._native is not None:
+                self._native.free()
+            self._native = NativeComm(solver, total, self.world, self.rank, self.addr, self.port + 23)
+
+    def barrier(self, solver=None) -> None:
+        if solver is not None:
+            solver.synchronize()
+        if self._native is not None:
+            self._native.allreduce_max(0.0)
+        if self._dist is not None:
+            import torch
+
+            if self.on_gpu:
+                torch.cuda.synchronize()
+            self._dist.barrier()
+            if self.on_gpu:
+                torch.cuda.synchronize()
+
+    def max(self, value: float) -> float:
+        if self._native is not None:
+            return self._native.allreduce_max(value)
+        if self._dist is not None:
+            import torch
+
+            t = torch.tensor([value], dtype=torch.float64, device="cuda" if self.on_gpu else "cpu")
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+            return float(t.item())
+        return float(value)
+
+    def sum(self, value: float) -> float:
+        """Sum over the ranks of a host scalar (bookkeeping of the sharded configurations: solved instances, cars alive)."""
+        if self._dist is not None:
+            import torch
+
+            t = torch.tensor([value], dtype=torch.float64, device="cuda" if self.on_gpu else "cpu")
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+            return float(t.item())
+        if self._native is not None:        # the communicator's one reduction is max: rank r's value is the max of (value on r, -inf elsewhere)
+            return float(np.sum([self._native.allreduce_max(value if self.rank == r else -np.inf) for r in range(self.world)]))
+        return float(value)
+
+    def gather_results(self, solver):
+        """``(u0 (total, 2), status (total,))`` of every instance of the job in global order, on every rank."""
+        if self._native is not None:
+            return self._native.allgather_results()
+        if self._dist is not None:
+            import torch
+
+            B = solver.B
+            if self.on_gpu:
+                u0_dev = torch.empty((B, 2), dtype=torch.float64, device="cuda")
+                st_dev = torch.empty((B,), dtype=torch.int32, device="cuda")
+                solver.get_u0_device(u0_dev.data_ptr()); solver.get_status_device(st_dev.data_ptr()); solver.synchronize()
+            else:
+                u0_dev = torch.from_numpy(solver.get_u0()); st_dev = torch.from_numpy(solver.get_status().copy())
+            u0_all = all_gather_blocks(u0_dev, self.total)
+            st_all = all_gather_blocks(st_dev, self.total)
+            if self.on_gpu:
+                torch.cuda.synchronize()
+            return u0_all.cpu().numpy(), st_all.cpu().numpy()
+        return solver.get_u0(), solver.get_status()
+
+    def describe(self) -> str:
+        return {"none": "none (one GPU)", "rccl": "RCCL all-gather of (u0, status) behind the C ABI (ihm2mpc_comm_*, no PyTorch)",
+                "torch": f"torch.distributed ({'nccl = RCCL' if self.on_gpu else 'gloo'}) all_gather of (u0, status)"}[self.carrier]
+
+    def close(self) -> None:
+        if self._native is not None:
+            self._native.allreduce_max(0.0)
+            self._native.free(); self._native = None
+        if self._dist is not None:
+            self._dist.barrier()
+            self._dist.destroy_process_group(); self._dist = None
+
+
+def spawn_ranks(n: int, argv: list[str], extra_env: dict | None = None) -> int:
+    """Start ``n`` copies of ``argv`` -- one process per GPU, ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` / ``MASTER_*`` set as
+    ``torch.distributed.run`` would -- and wait for them.  The caller has not touched the GPU (children must not be forked from a
+    process that has).  Returns 0 if every rank did; otherwise the first failing rank's exit code, after stopping the others."""
+    import os
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:          # a rank that died leaves the others waiting in a collective: stop exactly those we started
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc

@@ -81,8 +81,9 @@ class AcadosSimSolver:
         so: AcadosOcpOptions = ocp.solver_options
         so.tf = 2 * self._T
         so.sim_integrator_type, so.sim_collocation_type = o.integrator_type, o.collocation_type
-        if self.dyn10:
-            so.sim_method_num_steps = 25         # of the (unused) carrier OCP
+        # sub-steps of the (never solved) carrier OCP: RK4 stays stable on the 1 ms torque lag whatever T is, so that
+        # ihm2mpc_create's stability check cannot refuse a plant that would never run RK4 on it
+        so.sim_method_num_steps = max(25, int(np.ceil(self._T / 2e-3)))
         n = p.size // 2
         self._solver = BatchedOcpSolver(ocp, self.B, p[:n], p[n:], device=self.device)
         return self._solver

@@ -282,14 +282,14 @@ int ihm2mpc_set_track_geometry(ihm2mpc_handle *h, const double *X_ref, const dou
 /* n_steps plant steps of length dt_sim (the node: 0.01 s), each RK4 x M_sim, under a constant u; host (B,8),(B,2) -> (B,8) */
 int ihm2mpc_sim_step_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double dt_sim, int32_t n_steps, double v_dyn,
                           const double *x, const double *u, double *x_next);
-/* Track::project (tracks.cpp:183-288) + the Frenet states of the control node (src/ihm2/src/mpc_control_node.cpp:142-157):
- * x_cart (B,8) -> x_frenet (B,8) = (s, n, psi, v_x, v_y, r, T, delta); s_guess (B) in: centre of the search window of
- * half-width s_tol (the node: 2.0), out: fmod(s + 0.05 v_x, lap length) */
 /* plant step of the 15-state Frenet model with wheel speeds, fdyn10 (python/models.py:609-801; the DYN10 plant of python/main.py:490-502):
  * x (B,15) = (s, n, psi, v_x, v_y, r, omega_FL, omega_FR, omega_RL, omega_RR, tau_FL, tau_FR, tau_RL, tau_RR, delta), u (B,5) = (four
  * torque commands, u_delta); RK4 x M_sim over the handle's dt on the handle's track tables.  The model is singular at standstill
  * (smooth_abs_nonzero(0) = 1e-6 in the slip-ratio denominators): moving cars only; the reference integrates it with Radau IIA x 100. */
 int ihm2mpc_sim_step_dyn10(ihm2mpc_handle *h, int32_t M_sim, const double *x, const double *u, double *x_next);
+/* Track::project (tracks.cpp:183-288) + the Frenet states of the control node (src/ihm2/src/mpc_control_node.cpp:142-157):
+ * x_cart (B,8) -> x_frenet (B,8) = (s, n, psi, v_x, v_y, r, T, delta); s_guess (B) in: centre of the search window of
+ * half-width s_tol (the node: 2.0), out: fmod(s + 0.05 v_x, lap length) */
 int ihm2mpc_project(ihm2mpc_handle *h, const double *x_cart, double *s_guess, double s_tol, double *x_frenet);
 /* device-resident Cartesian plant state for closed loops: sim_advance_cart = plant(x_cart, u0 of the last solve), then
  * x0 <- project(x_cart) */

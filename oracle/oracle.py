@@ -176,6 +176,24 @@ def sim_step_dyn10(x, u, s_ref, kappa_ref, M, dt=0.05):
     return xn
 
 
+def jac_dyn10(x, u, s_ref, kappa_ref):
+    """``fdyn10``: (f (15), d f / d x (15, 15)) at one point, by dual-number evaluation of the model's formulas."""
+    x, xp = _d(x); u, up = _d(u); sr, srp = _d(s_ref); kr, krp = _d(kappa_ref)
+    f = np.zeros(15); J = np.zeros((15, 15))
+    lib().orc_jac_dyn10(xp, up, srp, krp, C.c_int(sr.size), f.ctypes.data_as(_dp), J.ctypes.data_as(_dp))
+    return f, J
+
+
+def sim_step_dyn10_irk(x, u, s_ref, kappa_ref, M=100, dt=0.05, integrator=INTEG_IRK_RADAU4, newton_iter=3):
+    """``fdyn10`` plant step with the reference's integrator (python/main.py:395-400): 4-stage Radau IIA collocation, M steps over dt,
+    ``newton_iter`` Newton iterations per step (acados' default 3); x (B,15), u (B,5)."""
+    x, xp = _d(np.atleast_2d(x)); u, up = _d(np.atleast_2d(u)); sr, srp = _d(s_ref); kr, krp = _d(kappa_ref)
+    xn = np.zeros_like(x)
+    lib().orc_sim_step_dyn10_irk(C.c_int(x.shape[0]), C.c_int(integrator), C.c_int(M), C.c_int(newton_iter), C.c_double(dt), xp, up, srp, krp,
+                                 C.c_int(sr.size), xn.ctypes.data_as(_dp))
+    return xn
+
+
 class OracleProblem:
     """Holds the arrays of an ``orc_problem`` alive.  ``desc`` is a plain dict of numpy arrays and
     scalars (the product's ``OcpData.as_dict()`` produces exactly this)."""

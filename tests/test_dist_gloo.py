@@ -89,3 +89,63 @@ def test_two_rank_gloo_shard_and_gather(track):
     out = P.rti_step(x, u, x0, yref, yref_e, nthreads=2)
     np.testing.assert_array_equal(st, out["status"])
     np.testing.assert_allclose(u0, u[:, 0], rtol=1e-12, atol=1e-12)
+
+
+def test_global_monte_carlo_batch_is_the_concatenation_of_its_shards():
+    """bench.py --config 3: every rank cuts rows [lo, hi) out of ONE global (x0, track_id); any world size gives the single-handle batch."""
+    import bench
+    from ihm2_amd.track import track_table
+
+    plans = [track_table(t) for t in bench.ALL_TRACKS]
+    for total in (7, 50, 1001):
+        x0, tid = bench.monte_carlo_batch(plans, total)
+        assert np.array_equal(tid, np.arange(total) % 7)
+        for world in (1, 2, 3, 8):
+            parts = [shard_bounds(total, world, r) for r in range(world)]
+            assert np.array_equal(np.concatenate([x0[lo:hi] for lo, hi in parts]), x0)
+            assert np.array_equal(np.concatenate([tid[lo:hi] for lo, hi in parts]), tid)
+        for t, p in enumerate(plans):        # every instance starts on its own track
+            assert np.all((x0[tid == t, 0] >= 0) & (x0[tid == t, 0] < p.lap_length))
+
+
+def test_spawned_ranks_shard_a_non_divisible_batch_and_gather_in_global_order(tmp_path):
+    """ihm2_amd.dist.spawn_ranks (what `bench.py --gpus N` does without a launcher) + RankContext over gloo: three ranks, 20 instances
+    (7 + 7 + 6) on three tracks; the gathered result equals the single-process result of the whole batch."""
+    import bench
+    from conftest import make_ocp
+    from ihm2_amd.dist import spawn_ranks
+    from ihm2_amd.track import track_table
+    from oracle import oracle as orc
+
+    total, world = 20, 3
+    out = tmp_path / "gathered.npz"
+    rc = spawn_ranks(world, [os.path.join(ROOT, "tests", "_rank_worker.py"), "run", str(total), str(out)])
+    assert rc == 0
+    got = np.load(out)
+    assert int(got["world"]) == world and float(got["slowest"]) == float(world) and float(got["count"]) == float(total)
+    plans = [track_table(t) for t in bench.ALL_TRACKS[:3]]
+    x0, tid = bench.monte_carlo_batch(plans, total)
+    N = 8
+    s_ref = np.stack([p.s_ref for p in plans]); k_ref = np.stack([p.kappa_ref for p in plans])
+    P = orc.OracleProblem(make_ocp(N=N, M=20).flatten().as_dict(s_ref, k_ref))
+    x = np.repeat(x0[:, None, :], N + 1, axis=1).copy(); u = np.zeros((total, N, 2))
+    yref = np.zeros((total, N, 12)); yref[:, :, 0] = x0[:, 0:1] + 8.0 * np.arange(N)[None] / N
+    yref_e = np.zeros((total, 8)); yref_e[:, 0] = x0[:, 0] + 8.0
+    ref = P.rti_step(x, u, x0, yref, yref_e, track_id=tid, nthreads=2)
+    np.testing.assert_array_equal(got["status"], ref["status"])
+    np.testing.assert_allclose(got["u0"], u[:, 0], rtol=1e-12, atol=1e-12)
+
+
+def test_spawned_ranks_report_a_rank_that_dies(tmp_path):
+    from ihm2_amd.dist import spawn_ranks
+
+    rc = spawn_ranks(2, [os.path.join(ROOT, "tests", "_rank_worker.py"), "fail", "4", str(tmp_path / "none.npz")])
+    assert rc != 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

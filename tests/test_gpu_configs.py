@@ -310,3 +310,41 @@ def test_both_builds_agree_on_4096_instances(track, kind):
     okh = np.all(a["h_st"] == 0, axis=0)                      # histories are (n_steps, B, .)
     assert okh.mean() > 0.95
     assert _rel(a["h_u0"][:, okh], b["h_u0"][:, okh]) < 1e-9
+
+
+# ---- the per-GPU shares of configs[3] and configs[4] at full size, through the workloads bench.py runs ----
+def test_config3_per_gpu_share_on_all_seven_tracks():
+    """configs[3]'s share of one of 8 GPUs -- 8192 dynamic bicycles (un-crossed model), instance g on track g mod 7 over ALL seven tracks
+    of data/, soft track rows, failed instances re-initialised -- five closed-loop steps after three of warm-up: at least 90 % of the
+    solves succeed, every track contributes solved instances, and the gathered (u0, status) is what the handle holds."""
+    import bench
+    from ihm2_amd.dist import RankContext
+
+    ranks = RankContext()               # one rank: no exchange, same code path as the sharded run
+    ranks.total = 8192
+    r = bench.rti_throughput(model="fdyn6u", B=8192, steps=5, warmup=3, tracks=bench.ALL_TRACKS, terminal_bounds="stage", track_rows="soft",
+                             recover=True, ranks=ranks)
+    assert r["tracks"] == 7 and r["ok_fraction"] >= 0.90, r
+    u0, st = r["gathered"]
+    assert u0.shape == (8192, 2) and st.shape == (8192,)
+    tid = np.arange(8192) % 7
+    for t in range(7):
+        assert np.mean(st[tid == t] == 0) >= 0.80, (bench.ALL_TRACKS[t], np.bincount(st[tid == t], minlength=5))
+    okm = st == 0
+    assert np.all(np.abs(u0[okm, 0]) <= 500.0 * (1 + 1e-9)) and np.all(np.abs(u0[okm, 1]) <= 0.5 * (1 + 1e-9))
+
+
+def test_config4_full_size_closed_loop_and_per_gpu_share():
+    """configs[4]: 4096 cars x 200 control periods device-resident (one ihm2mpc_step per period), and the share of one of 8 GPUs -- 512 cars --
+    both device-resident and in ONE persistent launch: the cars keep driving (alive + finished), and the two runners of the share agree car
+    by car (same freezing rules on the host and on the device)."""
+    import bench
+
+    kw = dict(steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0))
+    full = bench.closed_loop_config5(B=4096, device_loop=True, **kw)
+    assert full["steps"] == 200 and full["alive"] + full["finished"] >= 4080, full
+    dev = bench.closed_loop_config5(B=512, device_loop=True, **kw)
+    per = bench.closed_loop_config5(B=512, persistent=True, **kw)
+    assert dev["alive"] + dev["finished"] == 512 and per["alive"] + per["finished"] == 512, (dev, per)
+    assert (dev["alive"], dev["finished"], dev["failed"]) == (per["alive"], per["finished"], per["failed"])
+    assert abs(dev["progress_m_median"] - per["progress_m_median"]) <= 1e-6 * (1 + abs(dev["progress_m_median"]))

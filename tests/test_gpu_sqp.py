@@ -166,3 +166,30 @@ def test_live_solver_options_sqp_with_irk_match_oracle(track, model):
     s2, _, _, _, _, _ = _setup(track, model, "hard", B, 31, nlp_solver_max_iter=2, integrator_type="IRK", sim_method_num_steps=1)
     st2 = s2.solve()
     assert np.all(np.isin(st2, (0, 1, 2, 4))) and np.isin(st2, (0, 2)).mean() >= (0.9 if model == "fkin6" else 0.5)
+
+
+def test_long_backtracking_ladder_with_irk_matches_oracle_and_over_long_ladders_are_refused(track):
+    """alpha_reduction close to 1 makes a long ladder of trial steps.  The collocation path keeps one rollout per step length of
+    the ladder in a buffer: 59 step lengths (rho = 0.95, alpha_min = 0.05) run and agree with the oracle's step lengths; a ladder beyond the
+    buffer's limit of 64 (rho = 0.97: 99 step lengths) is refused by ihm2mpc_set_sqp_options instead of running past the buffer."""
+    B = 40
+    s, P, data, x0, yref, yref_e = _setup(track, "fkin6", "hard", B, 7, nlp_solver_max_iter=1, integrator_type="IRK", sim_method_num_steps=1)
+    s.set_sqp_options(alpha_min=0.05, alpha_reduction=0.95, tol=data.sqp_tol)
+    x, u = s.get_x(), s.get_u()
+    pi = np.zeros((B, N + 1, 8)); lam = np.zeros((B, N + 1, 28)); sl = np.zeros((B, N + 1, 28))
+    n_short = 0
+    for it in range(2):
+        status = s.solve()
+        out = P.sqp_solve(x, u, x0, yref, yref_e, pi=pi, lam=lam, sl=sl, max_iter=1, tol=data.sqp_tol, alpha_min=0.05, alpha_reduction=0.95)
+        st = s.get_sqp_stats()
+        both = (status == out["status"]) & np.isin(status, (0, 2))
+        assert both.sum() >= 0.9 * B
+        same = both & (np.abs(st["alpha"] - out["alpha"]) < 1e-12)
+        assert same.sum() >= 0.9 * both.sum()          # a merit tie at rounding level may fall one rung either way
+        assert _rel(s.get_x()[same], x[same]) < 1e-6 and _rel(s.get_u()[same], u[same]) < 1e-6          # tolerance 1e-6 relative
+        n_short += int((out["alpha"][same] < 1.0).sum())
+        s.set_x(x); s.set_u(u); s.set_multipliers(pi, lam); s.set_slacks(sl)
+    assert n_short >= 1
+    with pytest.raises(RuntimeError, match="ladder"):
+        s.set_sqp_options(alpha_min=0.05, alpha_reduction=0.97)
+    s.set_sqp_options(globalization="FIXED_STEP", alpha_min=0.05, alpha_reduction=0.97)        # no ladder without the line search
