@@ -5,8 +5,10 @@ control step call the controller, advance the plant in Frenet coordinates with t
 abort an instance on NaN, stop it one metre after a full lap, report lap time / mean speed / controller
 run time (``:561-575``).  Plant variants ``SimModelVariant`` (``python/main.py:337-341``,
 ``new_python/closed_loop_sim.py:27-31``): KIN6, DYN6, KIN6_DYN6 (speed switch ``v^2 sin(beta)/l_R <= 3``,
-``python/main.py:482-489``).  The reference integrates the plant with IRK Radau-IIA, 4 stages x 100 steps
-(``python/main.py:395-400``); here the plant is RK4 with ``M_sim`` sub-steps (default 100).
+``python/main.py:482-489``), DYN10 (the 15-state plant with wheel speeds under the Stanley controller, ``python/main.py:459-465,490-502``:
+:class:`Dyn10Simulator`, :func:`run_closed_loop_dyn10`).  The reference integrates the plants with IRK Radau-IIA, 4 stages x 100 steps
+(``python/main.py:395-400``): the DYN10 plant does the same here (from rest), the 8-state plants of the batched NMPC loop are RK4 with
+``M_sim`` sub-steps (default 100; ``ihm2mpc_sim_step`` also offers Radau IIA).
 
 Names kept from the refactor skeleton: ``SimulatorConfig`` (sic ``colloaction_type``), ``Simulator``,
 ``MultiModelSimulator`` (``new_python/simulator.py:25-62``), ``closed_loop`` with its argument list
@@ -29,7 +31,7 @@ class SimModelVariant(Enum):
     KIN6 = auto()
     DYN6 = auto()
     KIN6_DYN6 = auto()
-    DYN10 = auto()          # not implemented
+    DYN10 = auto()          # 15 states, Stanley controller: Dyn10Simulator / run_closed_loop_dyn10 below
     DYN6U = auto()          # DYN6 / KIN6_DYN6 with un-crossed slip angles (named deviation from quirk Q3)
     KIN6_DYN6U = auto()
 
@@ -145,6 +147,81 @@ def run_closed_loop_cartesian(controller: IHM2Controller, simulator: CartesianSi
     res = ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
     res.progress = progress
     return res
+
+
+class Dyn10Simulator:
+    """The DYN10 plant of ``python/main.py:395-428,490-502``: ``fdyn10`` (15 states: Frenet pose, velocities, four wheel speeds, four
+    wheel torques, steering) under ``AcadosSimOpts(T = dt, num_stages = 4, num_steps = 100, "IRK", "GAUSS_RADAU_IIA")``, for a batch of cars.
+    ``simulate(x (B,15), u (B,2))`` splits the torque command over the wheels as the reference's loop does."""
+
+    def __init__(self, plan: MotionPlan, batch_size: int = 1, sampling_time: float = 0.05, num_steps: int = 100, device: int = 0,
+                 car: "CarParams | None" = None):
+        from . import ocp as O
+        from .car_params import default_car_params
+        from .sim import AcadosSimOpts, generate_sim_solver
+
+        self.car = default_car_params() if car is None else car
+        self.B, self.dt = int(batch_size), float(sampling_time)
+        model = O.get_acados_model_from_implicit_dynamics("ihm2_fdyn10", O.fdyn10_model, 15, 5, 2 * plan.s_ref.size)
+        opts = AcadosSimOpts(T=self.dt, num_stages=4, num_steps=num_steps, integrator_type="IRK", collocation_type="GAUSS_RADAU_IIA")
+        self.sim = generate_sim_solver(model, opts, "", generate=False, build=False, batch_size=self.B, device=device)
+        self.sim.set("p", np.append(plan.s_ref, plan.kappa_ref))                          # python/main.py:432-435
+
+    def initial_state(self, s0: float = -6.0) -> np.ndarray:
+        """``python/main.py:438-441``: the car stands at ``s = s0`` on the centre line."""
+        from .car_params import CarState
+
+        return np.tile(CarState().to_frenet_dyn10(s0, 0.0, 0.0), (self.B, 1))
+
+    def wheel_commands(self, u: np.ndarray) -> np.ndarray:
+        """``python/main.py:492-500``: a quarter of the torque command on every wheel (within the wheel's limit), the steering command as is."""
+        u = np.asarray(u, dtype=np.float64).reshape(self.B, 2)
+        tau = np.clip(0.25 * u[:, 0], -self.car.actuator_params.wheel_torque_max, self.car.actuator_params.wheel_torque_max)
+        return np.column_stack([tau, tau, tau, tau, u[:, 1]])
+
+    def simulate(self, x: np.ndarray, u: np.ndarray) -> np.ndarray:
+        self.sim.set("x", np.asarray(x, dtype=np.float64).reshape(self.B, 15)); self.sim.set("u", self.wheel_commands(u))
+        self.sim.solve()                                     # a car whose step fails comes back as a NaN row (the loop stops that car)
+        return np.asarray(self.sim.get("x")).reshape(self.B, 15)
+
+    def free(self) -> None:
+        self.sim.free()
+
+
+def run_closed_loop_dyn10(plan: MotionPlan, n_steps: int = 501, batch_size: int = 1, v_x_ref=5.0, dt: float = 0.05, device: int = 0,
+                          interation_end_callback: Callable | None = None) -> "ClosedLoopResult":
+    """The reference's MiL loop with ``sim_model_variant = DYN10`` as it runs (``python/main.py:438-517``): from rest at ``s = -6``, the
+    Stanley controller (``:459-465``; the NMPC call at ``:457`` is commented out there and would be handed the 15-state vector) tracks
+    ``v_x_ref`` (a scalar or one value per car), the plant is ``fdyn10`` under Radau IIA; a NaN state stops a car, ``s > lap + 1`` ends its lap."""
+    from .controller import StanleyController
+
+    B = int(batch_size)
+    sim = Dyn10Simulator(plan, B, dt, device=device)
+    ctrl = StanleyController(dt=dt)
+    x = sim.initial_state()
+    v_ref = np.broadcast_to(np.asarray(v_x_ref, dtype=np.float64), (B,))
+    xs, us, sts, runtimes, alive_hist = [x.copy()], [], [], [], []
+    alive = np.ones(B, dtype=bool); finished = np.zeros(B, dtype=bool); lap_time = np.full(B, np.nan)
+    for i in range(n_steps):
+        alive_hist.append(alive.copy())
+        t0 = time.perf_counter()
+        u = ctrl.compute_control(n=x[:, 1], psi=x[:, 2], v_x=x[:, 3], v_x_ref=v_ref, kappa_ref=np.interp(x[:, 0], plan.s_ref, plan.kappa_ref))
+        runtimes.append((time.perf_counter() - t0) * 1e3)
+        u = np.where(alive[:, None], u, 0.0)
+        xn = sim.simulate(x, u)
+        nan = alive & np.any(np.isnan(xn), axis=1)          # python/main.py:503-504
+        alive &= ~nan
+        x = np.where(alive[:, None], xn, x)
+        done = alive & (x[:, 0] > plan.lap_length + 1.0)    # python/main.py:514-517
+        lap_time[done] = (i + 1) * dt
+        finished |= done; alive &= ~done
+        xs.append(x.copy()); us.append(u); sts.append(np.where(nan, 1, 0).astype(np.int32))
+        if interation_end_callback is not None:
+            interation_end_callback(i, x, u, sts[-1])
+        if not alive.any():
+            break
+    sim.free()
+    return ClosedLoopResult(np.array(xs), np.array(us), np.array(sts), alive, finished, lap_time, runtimes, np.array(alive_hist))
 
 
 class MultiModelSimulator(Simulator):

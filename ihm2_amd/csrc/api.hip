@@ -1059,11 +1059,15 @@ int ihm2mpc_sim_step_dyn10(ihm2mpc_handle *h, int32_t M_sim, const double *x, co
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (!x || !u || !x_next) return fail("null argument");
     if (M_sim < 1) return fail("M_sim must be >= 1");
-    if (rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the torque lags (t_T = 1e-3 s): use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
+    const bool irk = h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK;
+    if (!irk && rk4_unstable(h->cfg.dt, M_sim)) return fail("RK4 with M_sim = %d sub-steps of dt = %g is unstable on the torque lags (t_T = 1e-3 s): use M_sim >= %d", M_sim, h->cfg.dt, (int)ceil(h->cfg.dt / (2.78 * 1e-3)));
     if (!h->dyn10) { HIP_TRY(hipMalloc((void **)&h->dyn10, (size_t)h->B * 35 * sizeof(double))); }
     double *xs = h->dyn10, *us = h->dyn10 + (size_t)h->B * 15, *xn = h->dyn10 + (size_t)h->B * 20;
     if (upload(h, x, xs, 15) || upload(h, u, us, 5)) return -1;
-    ihm2_launch_sim_dyn10(h, M_sim, xs, us, xn, h->stream);
+    // the handle's plant integrator (python/main.py:395-400: IRK, GAUSS_RADAU_IIA): collocation steps of at most dt / M_sim, each
+    // solved to convergence within IHM2MPC_DYN10_NEWTON_MAX Newton iterations or cut (kernels_dyn10.hip) -- usable from rest
+    if (irk) ihm2_launch_sim_dyn10_irk(h, h->cfg.sim_integrator_type, M_sim, IHM2MPC_DYN10_NEWTON_MAX, xs, us, xn, h->stream);
+    else ihm2_launch_sim_dyn10(h, M_sim, xs, us, xn, h->stream);
     HIP_TRY(hipGetLastError());
     return download(h, xn, x_next, 15);
 }

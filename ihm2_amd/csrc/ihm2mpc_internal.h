@@ -129,6 +129,7 @@ struct ihm2mpc_handle {
 void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream);
 void ihm2_launch_build_tracks(ihm2mpc_handle *h, int max_seg, const int32_t *nseg, const double *cX, const double *cY, double *work);
 void ihm2_launch_sim_dyn10(ihm2mpc_handle *h, int M, const double *x, const double *u, double *xn, hipStream_t stream);
+void ihm2_launch_sim_dyn10_irk(ihm2mpc_handle *h, int integ, int M, int newton_iter, const double *x, const double *u, double *xn, hipStream_t stream);
 void ihm2_launch_wrap_lap(ihm2mpc_handle *h);
 void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_failed);
 void ihm2_launch_linearize(ihm2mpc_handle *h);

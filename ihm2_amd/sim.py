@@ -41,7 +41,7 @@ class AcadosSim:
 
 
 class AcadosSimSolver:
-    """``acados_template.AcadosSimSolver`` for the models of this build (``fkin6``, ``fdyn6``, ``fdyn6u``; ``fdyn10`` with RK4), batched."""
+    """``acados_template.AcadosSimSolver`` for the models of this build (``fkin6``, ``fdyn6``, ``fdyn6u``, ``fdyn10``), batched."""
 
     def __init__(self, sim: AcadosSim, json_file: str | None = None, verbose: bool = False, batch_size: int = 1, device: int = 0, **kwargs):
         o = sim.solver_options
@@ -49,15 +49,13 @@ class AcadosSimSolver:
             raise ValueError("4 stages: the classical RK4 (ERK) or 4-stage collocation (IRK), python/main.py:397")
         if o.integrator_type not in ("ERK", "IRK"):
             raise ValueError(f"integrator_type {o.integrator_type!r}")
-        if o.integrator_type == "IRK" and o.newton_iter != 3:
-            raise ValueError("the IRK integrator runs acados' default of 3 Newton iterations per step")
         self.sim, self.B, self.device = sim, int(batch_size), int(device)
         self.model_id = sim.model.model_id
-        # fdyn10 (python/models.py:609-801; the DYN10 plant of python/main.py:490-502): 15 states, 5 inputs, explicit RK4 only
+        if o.integrator_type == "IRK" and o.newton_iter != 3 and sim.model.kind != "fdyn10":
+            raise ValueError("the IRK integrator runs acados' default of 3 Newton iterations per step")
+        # fdyn10 (python/models.py:609-801; the DYN10 plant of python/main.py:490-502): 15 states, 5 inputs; "IRK" = the reference's
+        # Radau IIA x num_steps solved to convergence (usable from rest, python/main.py:438-441), "ERK" = RK4 x num_steps (moving cars)
         self.dyn10 = sim.model.kind == "fdyn10"
-        if self.dyn10 and o.integrator_type != "ERK":
-            raise ValueError('fdyn10 is integrated with RK4 x num_steps here (integrator_type = "ERK"); the reference uses Radau IIA x 100: '
-                             "the implicit integrators of this build are written for the 8-state models")
         self.nx, self.nu = (15, 5) if self.dyn10 else (NX, NU)
         self._T = float(o.T)
         self._p = None if sim.parameter_values is None else np.asarray(sim.parameter_values, dtype=float).ravel()

@@ -284,8 +284,15 @@ int ihm2mpc_sim_step_cart(ihm2mpc_handle *h, int32_t model, int32_t M_sim, doubl
                           const double *x, const double *u, double *x_next);
 /* plant step of the 15-state Frenet model with wheel speeds, fdyn10 (python/models.py:609-801; the DYN10 plant of python/main.py:490-502):
  * x (B,15) = (s, n, psi, v_x, v_y, r, omega_FL, omega_FR, omega_RL, omega_RR, tau_FL, tau_FR, tau_RL, tau_RR, delta), u (B,5) = (four
- * torque commands, u_delta); RK4 x M_sim over the handle's dt on the handle's track tables.  The model is singular at standstill
- * (smooth_abs_nonzero(0) = 1e-6 in the slip-ratio denominators): moving cars only; the reference integrates it with Radau IIA x 100. */
+ * torque commands, u_delta), over the handle's dt on the handle's track tables, with the handle's plant integrator
+ * (ihm2mpc_config.sim_integrator_type):
+ *   IHM2MPC_INTEG_IRK_RADAU4 -- replaces AcadosSimSolver.simulate of python/main.py:395-400,490-502 (IRK, GAUSS_RADAU_IIA, 4 stages,
+ *     num_steps = M_sim): collocation steps of at most dt / M_sim, each solved to convergence (at most IHM2MPC_DYN10_NEWTON_MAX Newton
+ *     iterations, else the step is cut by four), so that the reference's start at REST (python/main.py:438-441) integrates -- at
+ *     standstill the slip-ratio denominators smooth_abs_nonzero(0) = 1e-6 defeat a fixed number of Newton iterations; NaN rows if a
+ *     step cannot be made;
+ *   IHM2MPC_INTEG_ERK -- RK4 x M_sim, for moving cars only. */
+#define IHM2MPC_DYN10_NEWTON_MAX 10
 int ihm2mpc_sim_step_dyn10(ihm2mpc_handle *h, int32_t M_sim, const double *x, const double *u, double *x_next);
 /* Track::project (tracks.cpp:183-288) + the Frenet states of the control node (src/ihm2/src/mpc_control_node.cpp:142-157):
  * x_cart (B,8) -> x_frenet (B,8) = (s, n, psi, v_x, v_y, r, T, delta); s_guess (B) in: centre of the search window of

@@ -191,8 +191,9 @@ void orc_sim_step_dyn10(int B, int M, double dt, const double *x, const double *
                         double *xnext);
 /* f (15) and d f / d x (15 x 15, row-major) by dual-number evaluation of the same formulas */
 void orc_jac_dyn10(const double *x, const double *u, const double *s_ref, const double *kappa_ref, int nknots, double *f, double *J);
-/* the reference's plant integrator (python/main.py:395-400: IRK, 4 Radau IIA stages, 100 steps over dt): M collocation steps with
- * newton_iter Newton iterations each (acados' default: 3, fresh Jacobians); usable from rest (python/main.py:438-441) */
+/* the reference's plant integrator (python/main.py:395-400: IRK, 4 Radau IIA stages, 100 steps over dt): collocation steps of at most
+ * dt / M, each solved to convergence (at most newton_iter Newton iterations with fresh Jacobians, else the step is cut by four);
+ * usable from rest (python/main.py:438-441); NaN if a step cannot be made */
 void orc_sim_step_dyn10_irk(int B, int integrator, int M, int newton_iter, double dt, const double *x, const double *u, const double *s_ref,
                             const double *kappa_ref, int nknots, double *xnext);
 

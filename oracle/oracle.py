@@ -184,9 +184,9 @@ def jac_dyn10(x, u, s_ref, kappa_ref):
     return f, J
 
 
-def sim_step_dyn10_irk(x, u, s_ref, kappa_ref, M=100, dt=0.05, integrator=INTEG_IRK_RADAU4, newton_iter=3):
-    """``fdyn10`` plant step with the reference's integrator (python/main.py:395-400): 4-stage Radau IIA collocation, M steps over dt,
-    ``newton_iter`` Newton iterations per step (acados' default 3); x (B,15), u (B,5)."""
+def sim_step_dyn10_irk(x, u, s_ref, kappa_ref, M=100, dt=0.05, integrator=INTEG_IRK_RADAU4, newton_iter=10):
+    """``fdyn10`` plant step with the reference's integrator (python/main.py:395-400): 4-stage Radau IIA collocation on a grid of at most
+    dt / M, every step solved to convergence (at most ``newton_iter`` Newton iterations, else the step is cut); x (B,15), u (B,5)."""
     x, xp = _d(np.atleast_2d(x)); u, up = _d(np.atleast_2d(u)); sr, srp = _d(s_ref); kr, krp = _d(kappa_ref)
     xn = np.zeros_like(x)
     lib().orc_sim_step_dyn10_irk(C.c_int(x.shape[0]), C.c_int(integrator), C.c_int(M), C.c_int(newton_iter), C.c_double(dt), xp, up, srp, krp,
