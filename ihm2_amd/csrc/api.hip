@@ -186,7 +186,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(x, B * NS * 8); DA(u, B * N * 2); DA(x0, B * 8); DA(yref, B * N * 12); DA(yref_e, B * 8);
     DA(pi, B * NS * 8); DA(lam, B * NS * NLAM); DA(res, B * 4); DA(qp_res, B * 4); DA(status, B); DA(qp_iter, B); DA(active, B); DA(u0, B * 2);
     DA(lin, (B * N + B) * LIN_REC);      // + one spare record per instance (the kinematic plant's, never read)
-    DA(q_g, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, (B * N + 2 * QM_PAD) * 64); DA(scratch, B * 24);
+    DA(q_g, B * NS * 10); DA(q_rg, B * NS * 10); DA(q_P, B * NS * 64); DA(q_M, (B * N + 2 * QM_PAD) * 64); DA(scratch, B * 24);
 #undef DA
     if (ihm2_upload_irk_tab(h)) return fail("could not upload the collocation tableau");
     *out = h;
@@ -201,7 +201,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
                     h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
-                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
+                    h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_rg, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc, h->ls_pending, h->irk_tab,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -98,6 +98,7 @@ struct ihm2mpc_handle {
     double *lin;    // (B,N,96) linearisation records [A | B | b | rb], then B spare records (the kinematic plant's by-product)
     // ---- QP workspace in HBM/L2 (everything else of the QP lives in LDS / registers) ----
     double *q_g;    // (B,NS,10) QP gradient
+    double *q_rg;   // (B,NS,10) stationarity residual of the interior-point iterate (follows the step between two evaluations from the data)
     double *q_P;    // (B,NS,64) Riccati matrices of the current factorisation
     double *q_M;    // (QM_PAD + B*N + QM_PAD, 64) closed-loop matrices A - B K (row-major; the vector recursion reads them
                     // transposed), padded at both ends: the sweeps' prefetch rings run QM_PAD rows past an instance unclamped

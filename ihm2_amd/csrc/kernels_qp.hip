@@ -7,6 +7,10 @@
 //        lb - c(z) <= R_k z_k <= ub - c(z)   (8 state boxes, 2 input boxes, 2 general rows [C D], 2 track rows h;
 //                                             any side may be soft: slack s >= 0 with cost z s + 1/2 Z s^2)
 // H_k = cost_scale * V'W_kV is constant and shared by the batch (python/mpc.py:49-64); g_k = H_k z_k - Gy_k yref_k.
+// Residuals: the stationarity and dynamics residuals are formed from the problem data (one pass over the records) at the first
+// iterate; afterwards they FOLLOW THE STEP -- the Newton step solves the linearised rows exactly, so r_b <- (1 - alpha) r_b and
+// r_g <- (1 - alpha_d) r_g + (alpha - alpha_d) H dz -- and are formed from the data once more when they pass the convergence test
+// (the rounding error of the Riccati solve against the barrier-augmented Hessian is invisible to the recursion).
 // Solver: Mehrotra predictor-corrector primal-dual interior point with separate primal / dual step lengths; the Newton
 // system is reduced to an equality-constrained LQ problem solved by a Riccati recursion (soft sides: their slack block is
 // eliminated per constraint first).  Tolerances are relative to sg = max(1,|g|_inf) and sb = max(1,|b|_inf,|dx0|_inf).
@@ -53,7 +57,7 @@ struct QpArgs {
     double *pi, *lam, *res, *qp_res, *u0;
     int32_t *status, *qp_iter;
     const double *lin;
-    double *g, *P, *M, *slk;
+    double *g, *rg, *P, *M, *slk;
     // track rows
     const int32_t *track_id;
     const double *widths;
@@ -229,6 +233,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     const double *ub = a.u + (size_t)b * N * 2;
     const double *linb = a.lin + (size_t)b * N * LIN_REC;
     double *gb = a.g + (size_t)b * NS * 10;
+    double *rgb = a.rg + (size_t)b * NS * 10;
     double *Pg = a.P + (size_t)b * NS * 64;
     double *Mg = a.M + (size_t)b * N * 64;
     double *pib = a.pi + (size_t)b * NS * 8;
@@ -418,6 +423,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 
     // ------------------------------------------------------------------ interior-point iterations
     int qstatus = 1, it = 0;
+    bool exact_mode = false;     // residuals from the problem data in every iteration (set when followed residuals failed their check)
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
     double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
     double pa_l[NSLOT], pa_u[NSLOT];      // dlam * dt of the predictor (only the products enter the corrector): 2 registers per slot less than the factors
@@ -449,57 +455,70 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 /*@S:14*/
         BSYNC();
         // ---- stationarity and dynamics residuals ----
-        // (i) terms without [A B]: g + H z - pi_k - R'(lam_l - lam_u)
-        // (an unrolled variant that forms all values before the first store -- QP gradient entries and LDS operands of all passes in
-        // flight together -- was 30 % faster here but cost the slot phases twice that in spilled slot registers)
-        for (int e = tid; e < NS * 10; e += NT) {
-            const int k = e / 10, j = e % 10;
-            double acc = gb[e];
-            if (HL && h_sparse) {
-                const int row = ((k == N) ? 10 : 0) + j;
+        // exact: formed from the problem data -- (i) the terms without [A B], g + H z - pi_k - R'(lam_l - lam_u), then (ii) [A B]'pi_{k+1}
+        // and r_b from the records.  Otherwise they are what the update at the end of the previous iteration left in rgb / rb: the
+        // Newton step solves the linearised rows exactly, so the residuals follow the step (no pass over the records).  Followed residuals
+        // that pass the convergence test are formed from the data and tested again; should that fail, every later iteration forms them
+        // from the data (exact_mode).
+        bool exact = (it == 0) || exact_mode, finished = false;
+        for (int rpass = 0; rpass < 2; rpass++) {
+            if (exact) {
+                // (an unrolled variant that forms all values before the first store -- QP gradient entries and LDS operands of all passes in
+                // flight together -- was 30 % faster here but cost the slot phases twice that in spilled slot registers)
+                for (int e = tid; e < NS * 10; e += NT) {
+                    const int k = e / 10, j = e % 10;
+                    double acc = gb[e];
+                    if (HL && h_sparse) {
+                        const int row = ((k == N) ? 10 : 0) + j;
 #pragma unroll
-                for (int q = 0; q < 3; q++) acc = fma(spv[row * 3 + q], z[k * 10 + spc[row * 3 + q]], acc);
-            } else {
+                        for (int q = 0; q < 3; q++) acc = fma(spv[row * 3 + q], z[k * 10 + spc[row * 3 + q]], acc);
+                    } else {
 #pragma unroll
-                for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
-            }
-            if (k < N) {
-                acc = fma(-CDV(k, 0, j), cf[k * NCK + 10], acc);
-                acc = fma(-CDV(k, 1, j), cf[k * NCK + 11], acc);
-            }
-            if (j < 8) acc -= pi[k * 8 + j];
-            acc -= cf[k * NCK + j];
-            if (PATH && (j == 1 || j == 2)) {
-                const double l12 = cf[k * NCK + 12], l13 = cf[k * NCK + 13];
-                acc -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
-            }
-            gt[e] = acc;
-        }
-#define NORMS_AND_CHECK() \
- \
-        res_g = 0.0; res_b = 0.0; \
-        for (int e = tid; e < NS * 10; e += NT) { \
-            const int k = e / 10, j = e % 10; \
-            double v = gt[e]; \
-            if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; } \
-            res_g = nanmax(res_g, fabs(v)); \
-        } \
-        for (int e = tid; e < N * 8; e += NT) res_b = nanmax(res_b, fabs(rb[e])); \
-        res_g = nanmax(res_g, res_gs); \
-        res_g = blk_nanmax(res_g); res_b = blk_nanmax(res_b); res_d = blk_nanmax(res_d); res_m = blk_nanmax(res_m); \
-        mu = blk_sum(mu_acc) * inv_m; \
-        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; break; } \
-        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { qstatus = 0; break; } \
-        if (it >= a.iter_max) { qstatus = 1; break; } \
-        BSYNC();
-        BSYNC();
+                        for (int l = 0; l < 10; l++) acc = fma(HS(k, j, l), z[k * 10 + l], acc);
+                    }
+                    if (k < N) {
+                        acc = fma(-CDV(k, 0, j), cf[k * NCK + 10], acc);
+                        acc = fma(-CDV(k, 1, j), cf[k * NCK + 11], acc);
+                    }
+                    if (j < 8) acc -= pi[k * 8 + j];
+                    acc -= cf[k * NCK + j];
+                    if (PATH && (j == 1 || j == 2)) {
+                        const double l12 = cf[k * NCK + 12], l13 = cf[k * NCK + 13];
+                        acc -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
+                    }
+                    gt[e] = acc;
+                }
+                BSYNC();
 /*@S:2*/
-        // (ii) [A B]' pi_{k+1} and the dynamics residual rb_k = A z_k + B u_k + b_k - z_{k+1} (LDS and slot 88 of the record, where
-        // the factor sweep picks it up): one dot product per lane, all stages in parallel
-        dyn_residual<4, NT>(N, tid, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
-        BSYNC();
+                // (ii) [A B]' pi_{k+1} and the dynamics residual rb_k = A z_k + B u_k + b_k - z_{k+1} (LDS and slot 88 of the record, where
+                // the factor sweep picks it up): one dot product per lane, all stages in parallel
+                dyn_residual<4, NT>(N, tid, const_cast<double *>(linb), z, pi, gt, rb, LIN_REC);
+                BSYNC();
+            }       // (otherwise gt already holds the followed residual: the update at the end of the previous iteration left it there)
 /*@S:3*/
-        NORMS_AND_CHECK()
+            res_g = 0.0; res_b = 0.0;
+            for (int e = tid; e < NS * 10; e += NT) {
+                const int k = e / 10, j = e % 10;
+                double v = gt[e];
+                if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
+                if (exact) rgb[e] = v;          // the residual the update at the end of the iteration carries on
+                res_g = nanmax(res_g, fabs(v));
+            }
+            for (int e = tid; e < N * 8; e += NT) res_b = nanmax(res_b, fabs(rb[e]));
+            res_g = nanmax(res_g, res_gs);
+            res_g = blk_nanmax(res_g); res_b = blk_nanmax(res_b);
+            if (rpass == 0) { res_d = blk_nanmax(res_d); res_m = blk_nanmax(res_m); mu = blk_sum(mu_acc) * inv_m; }
+            if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; finished = true; break; }
+            if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) {
+                if (exact) { qstatus = 0; finished = true; break; }
+                exact = true; exact_mode = true;        // the followed residuals say converged: check against the data
+                continue;
+            }
+            break;
+        }
+        if (finished) break;
+        if (it >= a.iter_max) { qstatus = 1; break; }
+        BSYNC();
         // separate step lengths for the primal (z, t, s) and the dual (pi, lam, lam_s) variables, as HPIPM's split_step
         double alpha = 1.0, alpha_d = 1.0, sigma = 0.0;
 /*@S:4*/
@@ -574,7 +593,6 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (lane < 8) dz[lane] = 0.0;
         }
         BSYNC();
-#undef NORMS_AND_CHECK
         for (int pass = 0; pass < 2; pass++) {
             const double mu_t = fmax(sigma * mu, mu_floor);
             if (pass == 1) slot_coeffs(1);
@@ -781,6 +799,42 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         }
 /*@S:12*/
         if (fmin(alpha, alpha_d) < 1e-12) { qstatus = 2; break; }
+/*@S:17*/
+        if (!exact_mode) {
+            // residuals of the new iterate: r_g <- (1 - alpha_d) r_g + (alpha - alpha_d) H dz -> rgb (HBM/L2: the modified gradient in gt is
+            // dead by now, but r_g itself has to survive the next iteration's gradient modifications) and gt; r_b <- (1 - alpha) r_b -> LDS and
+            // the records' slot.  The old values of a batch are loaded before the first store (the stores would pin every later load behind
+            // them).  (Loading all of them ahead of the iterate's own update, to cover their latency, was tried: the eight live values spill
+            // the slot registers -- 904 k against 965 k solves/s over 20 steps.)
+            const double cd = 1.0 - alpha_d, cp = alpha - alpha_d, cb = 1.0 - alpha;
+            const int n10 = NS * 10;
+            for (int base = 0; base < n10; base += 4 * NT) {
+                double ro[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) ro[q] = rgb[min(base + NT * q + tid, n10 - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int e = base + NT * q + tid, ec = min(e, n10 - 1), k = ec / 10, j = ec % 10;
+                    double hdz = 0.0;
+                    if (HL && h_sparse) {
+                        const int row = ((k == N) ? 10 : 0) + j;
+#pragma unroll
+                        for (int l = 0; l < 3; l++) hdz = fma(spv[row * 3 + l], dz[k * 10 + spc[row * 3 + l]], hdz);
+                    } else {
+#pragma unroll
+                        for (int l = 0; l < 10; l++) hdz = fma(HS(k, j, l), dz[k * 10 + l], hdz);
+                    }
+                    const bool masked = (k == 0 && j < 8) || (k == N && j >= 8);
+                    const double v = masked ? 0.0 : fma(cp, hdz, cd * ro[q]);
+                    if (e < n10) { rgb[e] = v; gt[e] = v; }
+                }
+            }
+            for (int e = tid; e < N * 8; e += NT) {
+                const double v = cb * rb[e];
+                rb[e] = v;
+                const_cast<double *>(linb)[(size_t)(e >> 3) * LIN_REC + RIC_REC_RB + (e & 7)] = v;
+            }
+        }
         for (int e = tid; e < NS * 10; e += NT) z[e] = fma(alpha, dz[e], z[e]);
         for (int e = tid; e < NS * 8; e += NT) pi[e] = fma(alpha_d, pv[e], pi[e]);
 #pragma unroll
@@ -1045,7 +1099,7 @@ static QpArgs qp_args(ihm2mpc_handle *h)
     a.Hs = h->Hs; a.Gy = h->Gy; a.CD = h->CD; a.slot_lb = h->slot_lb; a.slot_ub = h->slot_ub; a.slot_kc = h->slot_kc;
     a.x = h->x; a.u = h->u; a.x0 = h->x0; a.yref = h->yref; a.yref_e = h->yref_e;
     a.pi = h->pi; a.lam = h->lam; a.res = h->res; a.qp_res = h->qp_res; a.u0 = h->u0; a.status = h->status; a.qp_iter = h->qp_iter;
-    a.lin = h->lin; a.g = h->q_g; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
+    a.lin = h->lin; a.g = h->q_g; a.rg = h->q_rg; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
     a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
     a.symmetrize = (h->cfg.model == IHM2MPC_MODEL_FDYN6) ? 1 : 0;

@@ -181,7 +181,7 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
     double s[(ORC_NMAX + 1) * 2 * NC], lams[(ORC_NMAX + 1) * 2 * NC], rs[(ORC_NMAX + 1) * 2 * NC], rm2[(ORC_NMAX + 1) * 2 * NC];
     double ds[(ORC_NMAX + 1) * 2 * NC], dlams[(ORC_NMAX + 1) * 2 * NC], ds_a[(ORC_NMAX + 1) * 2 * NC], dlams_a[(ORC_NMAX + 1) * 2 * NC];
     unsigned char act[(ORC_NMAX + 1) * 2 * NC], soft[(ORC_NMAX + 1) * 2 * NC];
-    int status = 1, it = 0, m_act = 0;
+    int status = 1, it = 0, m_act = 0, exact_mode = 0;
 #define SGN(i) ((((i) % (2 * NC)) < NC) ? 1.0 : -1.0)
 #define ROW(i) (((i) / (2 * NC)) * NC + ((i) % NC))
 
@@ -233,13 +233,26 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
     }
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
     for (it = 0;; it++) {
-        /* ---- residuals ---- */
+        /* ---- residuals ----
+         * The stationarity and dynamics residuals are formed from the problem data at the first iterate; afterwards they FOLLOW THE STEP
+         * (end of the loop): the Newton step solves the linearised rows exactly, so r_b <- (1 - alpha) r_b and
+         * r_g <- (1 - alpha_d) r_g + (alpha - alpha_d) H dz -- no pass over A, B per iteration.  What the recursion cannot see is the
+         * rounding error of the Riccati solve against the barrier-augmented Hessian (eps |H~| |dz|, which grows as the barrier weights
+         * lam / t do): when the followed residuals pass the convergence test they are formed from the data again and tested again;
+         * should that fail, the iteration goes on with residuals formed from the data in every iteration (exact_mode). */
+        int exact = (it == 0) || exact_mode;
+    recompute:
         res_g = res_b = res_d = res_m = 0; mu = 0;
         for (int k = 0; k < NS; k++) {
             for (int c = 0; c < NC; c++) {
                 double rz = 0;
                 for (int j = 0; j < NZ; j++) rz += R[(k * NC + c) * NZ + j] * z[k * NZ + j];
                 Rz[k * NC + c] = rz;
+            }
+            if (!exact) {
+                for (int j = 0; j < NZ; j++) res_g = fmax(res_g, fabs(rg[k * NZ + j]));
+                if (k < N) for (int i = 0; i < NX; i++) res_b = fmax(res_b, fabs(rb[k * NX + i]));
+                continue;
             }
             for (int j = 0; j < NZ; j++) {
                 double acc = g[k * NZ + j];
@@ -282,7 +295,11 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
         if (m_act > 0) mu /= m_act;
         if (orc_debug) fprintf(stderr, "ipm it %2d res_g %.3e res_b %.3e res_d %.3e res_m %.3e mu %.3e\n", it, res_g, res_b, res_d, res_m, mu);
         if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { status = 3; break; }
-        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) { status = 0; break; }
+        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) {
+            if (exact) { status = 0; break; }
+            exact = 1; exact_mode = 1;      /* the followed residuals say converged: check against the data */
+            goto recompute;
+        }
         if (it >= iter_max) { status = 1; break; }
 
         /* ---- barrier-augmented Hessian ---- */
@@ -364,6 +381,14 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
         for (int k = 0; k < NS; k++) {
             for (int j = 0; j < NZ; j++) z[k * NZ + j] += alpha * dz[k * NZ + j];
             for (int i = 0; i < NX; i++) pi[k * NX + i] += alpha_d * dpi[k * NX + i];
+            /* residuals of the new iterate (see above); the rows of x_0 and of the padded terminal inputs stay zero */
+            for (int j = 0; j < NZ; j++) {
+                if ((k == 0 && j < NX) || (k == N && j >= NX)) continue;
+                double hdz = 0;
+                for (int l = 0; l < NZ; l++) hdz += H[(k * NZ + j) * NZ + l] * dz[k * NZ + l];
+                rg[k * NZ + j] = (1.0 - alpha_d) * rg[k * NZ + j] + (alpha - alpha_d) * hdz;
+            }
+            if (k < N) for (int i = 0; i < NX; i++) rb[k * NX + i] *= (1.0 - alpha);
         }
         for (int i = 0; i < NI; i++)
             if (act[i]) {

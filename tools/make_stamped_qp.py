@@ -9,8 +9,8 @@ for f in os.listdir(dst):
 p = os.path.join(dst, "kernels_qp.hip"); s = open(p).read()
 NS = 32
 s = s.replace('#include "ihm2mpc_internal.h"', '#include "ihm2mpc_internal.h"\n#include <cstdio>', 1)
-assert "    double car_L, car_W;\n};" in s
-s = s.replace("    double car_L, car_W;\n};", "    double car_L, car_W;\n    long long *dbg;\n};")
+assert "    double car_L, car_W;\n" in s
+s = s.replace("    double car_L, car_W;\n", "    double car_L, car_W;\n    long long *dbg;\n", 1)
 s = s.replace("    // ---- LDS carve-up (doubles) ----", "    long long T[%d]; for (int q = 0; q < %d; q++) T[q] = 0; long long t_prev = __builtin_readcyclecounter(); int cur_sec = %d;\n#if QP_SET == 0 || defined(STAMP_SOFT)\n#define STAMP(i) do { long long t_now = __builtin_readcyclecounter(); T[cur_sec] += t_now - t_prev; t_prev = t_now; cur_sec = (i); } while (0)\n#else\n#define STAMP(i) do { (void)t_prev; (void)cur_sec; } while (0)   /* the soft / track-row set is built unstamped */\n#endif\n    // ---- LDS carve-up (doubles) ----" % (NS, NS, NS - 1))
 s = re.sub(r"/\*@S:(\d+)\*/", lambda m: "STAMP(%s);" % m.group(1), s)
 assert "        a.status[b] = st; a.qp_iter[b] = it;\n" in s

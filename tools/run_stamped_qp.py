@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ihm2_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "scratch", "csrc_dbg", "libihm2mpc_dbg.so")
+_lib.LIB_PATH = os.environ.get("IHM2_DBG_LIB", os.path.join(ROOT, "scratch", "csrc_dbg", "libihm2mpc_dbg.so"))
 import bench  # noqa: E402
 from ihm2_amd.solver import BatchedOcpSolver  # noqa: E402
 
