@@ -342,6 +342,9 @@ int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e)
     for (int k = 1; k < N && h->uniform_H; k++)
         for (int i = 0; i < 100; i++)
             if (Hs[(size_t)k * 100 + i] != Hs[i]) { h->uniform_H = false; break; }
+    for (int k = 1; k < N && h->uniform_H; k++)       // "uniform" covers the gradient map as well: the QP kernel keeps one copy of both
+        for (int i = 0; i < 120; i++)
+            if (Gy[(size_t)k * 120 + i] != Gy[i]) { h->uniform_H = false; break; }
     if (upload_shared(h, Hs.data(), h->Hs, Hs.size()) || upload_shared(h, Gy.data(), h->Gy, Gy.size())) return -1;
     if (upload_shared(h, W, h->Wd, (size_t)N * 144) || upload_shared(h, W_e, h->Wd + (size_t)N * 144, 64)) return -1;
     h->weights_set = true;

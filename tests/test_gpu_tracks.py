@@ -1,5 +1,6 @@
 """SURVEY.md section 8f N1 on the device: the track tables (python/motion_planning.py:139-289, 345-428) built by
-``ihm2mpc_build_tracks`` from the centre lines' spline coefficients against the host NumPy restatement (``ihm2_amd/track.py``)."""
+``ihm2mpc_build_tracks`` from the centre lines' spline coefficients, against the independent restatement ``oracle/track_np.py``
+(null-space spline fit, point-by-point sampling: tests/test_oracle_track.py pins it) -- and, as a second check, the product's host planner."""
 import numpy as np
 import pytest
 
@@ -21,6 +22,19 @@ def test_device_track_tables_match_the_host_planner_on_all_tracks():
     s = BatchedOcpSolver(make_ocp(), 70, dummy, np.zeros_like(dummy), track_id=np.arange(70) % len(names))
     s.build_tracks([c[0] for c in cs], [c[1] for c in cs])
     s_ref, kappa, X, Y, phi = s.get_tracks()
+    from oracle import track_np as OT
+    for t, n in enumerate(names):           # the checker is the oracle's own pipeline, fit included (not product code)
+        geo = T.load_track_geometry_data(n)
+        mp = OT.motion_plan(geo.center_line, geo.track_widths)
+        L = mp["lap_length"]
+        assert np.max(np.abs(s_ref[t] - mp["s_ref"])) < 1e-7 * L                                # tolerance 1e-7 of a lap (two different fits)
+        assert np.max(np.abs(X[t] - mp["X_ref"])) < 1e-7 * L and np.max(np.abs(Y[t] - mp["Y_ref"])) < 1e-7 * L
+        assert np.max(np.abs(kappa[t] - mp["kappa_ref"])) < 1e-6 * max(1.0, np.max(np.abs(mp["kappa_ref"])))
+        assert np.max(np.abs(np.angle(np.exp(1j * (phi[t] - mp["phi_ref"]))))) < 1e-6
+        # the device kernels alone (same coefficients in): 1e-9
+        mp2 = OT.motion_plan(geo.center_line, geo.track_widths, coeffs=cs[t])
+        assert np.max(np.abs(s_ref[t] - mp2["s_ref"])) < 1e-9 * L and np.max(np.abs(X[t] - mp2["X_ref"])) < 1e-9 * L
+        assert np.max(np.abs(kappa[t] - mp2["kappa_ref"])) < 1e-9 * max(1.0, np.max(np.abs(mp2["kappa_ref"])))
     for t, p in enumerate(plans):
         L = p.lap_length
         assert np.max(np.abs(s_ref[t] - p.s_ref)) < 1e-9 * L                                    # tolerance 1e-9 of a lap
