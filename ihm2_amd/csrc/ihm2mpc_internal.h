@@ -85,6 +85,8 @@ struct ihm2mpc_handle {
     double *ls_phi; // (n_alpha, B, N, 8) IRK rollouts at the trial points of the line search (SQP mode with the IRK integrator)
     int ls_nalpha;
     void *irk_tab;       // device copy of the OCP integrator's collocation tableau (irk_body.hpp: IrkTab), nullptr for ERK
+    void *sim_irk_tab;   // the same for the plant steps of the persistent loop (step dt / sim_irk_M), allocated on first use
+    int sim_irk_M;
     int32_t *ls_pending; // (B) instances whose line search goes past the first rollouts (two-launch ladder)
     double *dyn10;  // (B,35) staging of the fdyn10 plant: x (15), u (5), x_next (15); allocated on first use
     double *qp_res; // (B,4) KKT residuals of the QP at its returned point, relative to the scales of its tolerances
@@ -136,6 +138,7 @@ void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_fail
 void ihm2_launch_linearize(ihm2mpc_handle *h);
 // kernels_irk.hip: the collocation integrators (cfg.integrator_type / cfg.sim_integrator_type != IHM2MPC_INTEG_ERK)
 void ihm2_launch_linearize_irk(ihm2mpc_handle *h);
+int ihm2_upload_sim_irk_tab(ihm2mpc_handle *h, int M_sim);      // 0 ok (h->sim_irk_tab holds the plant tableau for M_sim steps)
 int ihm2_upload_irk_tab(ihm2mpc_handle *h);      // (re)builds h->irk_tab for the configured integrator and step; 0 ok
 void ihm2_launch_rollout_irk(ihm2mpc_handle *h, int j_begin, int j_end, double *phi, const int32_t *pending);
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream,

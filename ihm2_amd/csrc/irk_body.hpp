@@ -291,6 +291,30 @@ __device__ __forceinline__ void irk_linearize_quad(const int st, const IrkRows &
 }
 
 // one quad: Phi(xp_k + al (x_k - xp_k), up_k + al (u_k - up_k)) of one interval -> out (8), the line search's trial point
+// Plant step of one instance by its quad (python/main.py:395-400,476-502): x <- IRK x M over M steps of the tableau's h; model -1 / -2: the
+// kinematic / dynamic switch of python/main.py:482-489 (crossed / un-crossed slip angles), decided once at the start of the control period.
+// Every lane of the quad ends with the new state.  Shared by k_sim_irk and the persistent loop (bit-identical plant steps).
+__device__ __forceinline__ void irk_sim_quad(const int st, const IrkRows &rows, const int model, const int M, double (&x)[8], const double u_T, const double u_d,
+                                             TrackSeg &trk)
+{
+    int mdl = model;
+    if (model < 0) {
+        const double beta = atan(k_rwd * tan(x[7]));
+        const double v2 = x[3] * x[3] + x[4] * x[4];
+        mdl = (v2 * sin(beta) / k_lR <= 3.0) ? IHM2MPC_MODEL_FKIN6 : (model == -2 ? IHM2MPC_MODEL_FDYN6U : IHM2MPC_MODEL_FDYN6);
+    }
+    const double hb = rows.hb;
+    for (int m = 0; m < M; m++) {
+        double K[8], J[8][10];
+        // the model is the same for the four lanes of a quad; quads of a wave may differ (the branch re-converges per step)
+        if (mdl == IHM2MPC_MODEL_FKIN6) irk_step<IHM2MPC_MODEL_FKIN6, false>(st, rows, x, u_T, u_d, trk, K, J);
+        else if (mdl == IHM2MPC_MODEL_FDYN6) irk_step<IHM2MPC_MODEL_FDYN6, false>(st, rows, x, u_T, u_d, trk, K, J);
+        else irk_step<IHM2MPC_MODEL_FDYN6U, false>(st, rows, x, u_T, u_d, trk, K, J);
+#pragma unroll
+        for (int a = 0; a < 8; a++) x[a] += quad_sum(hb * K[a]);
+    }
+}
+
 template <int MODEL>
 __device__ __forceinline__ void irk_rollout_quad(const int st, const IrkRows &rows, const int M, const double al, const double *x, const double *xp,
                                                  const double *u, const double *up, const int tid, const int nknots, const double *__restrict__ s_ref,

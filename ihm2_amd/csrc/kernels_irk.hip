@@ -53,26 +53,9 @@ __global__ __launch_bounds__(64) void k_sim_irk(int B, int model, int M, IrkTab 
     const int tid = track_id[b];
     TrackSeg trk;
     trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
-    int mdl = model;
-    if (model < 0) {
-        const double beta = atan(k_rwd * tan(x[7]));
-        const double v2 = x[3] * x[3] + x[4] * x[4];
-        mdl = (v2 * sin(beta) / k_lR <= 3.0) ? IHM2MPC_MODEL_FKIN6 : (model == -2 ? IHM2MPC_MODEL_FDYN6U : IHM2MPC_MODEL_FDYN6);
-    }
     const bool frozen = active && !active[b];
     IRK_ROWS(rows, tab, st)
-    const double hb = rows.hb;
-    if (!frozen) {
-        for (int m = 0; m < M; m++) {
-            double K[8], J[8][10];
-            // the model is the same for the four lanes of a quad; quads of a wave may differ (the branch re-converges per step)
-            if (mdl == IHM2MPC_MODEL_FKIN6) irk_step<IHM2MPC_MODEL_FKIN6, false>(st, rows, x, u_T, u_d, trk, K, J);
-            else if (mdl == IHM2MPC_MODEL_FDYN6) irk_step<IHM2MPC_MODEL_FDYN6, false>(st, rows, x, u_T, u_d, trk, K, J);
-            else irk_step<IHM2MPC_MODEL_FDYN6U, false>(st, rows, x, u_T, u_d, trk, K, J);
-#pragma unroll
-            for (int a = 0; a < 8; a++) x[a] += quad_sum(hb * K[a]);
-        }
-    }
+    if (!frozen) irk_sim_quad(st, rows, model, M, x, u_T, u_d, trk);
     if (bq < B && st == 0)
 #pragma unroll
         for (int a = 0; a < 8; a++) xn[(size_t)b * 8 + a] = x[a];
@@ -180,6 +163,19 @@ int ihm2_upload_irk_tab(ihm2mpc_handle *h)
     if (!h->irk_tab && hipMalloc(&h->irk_tab, sizeof(IrkTab)) != hipSuccess) return 1;
     if (hipMemcpyAsync(h->irk_tab, &tab, sizeof(IrkTab), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
     return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 1;
+}
+
+// the plant's tableau for M_sim steps per control period, in device memory for the persistent loop (rebuilt when M_sim changes)
+int ihm2_upload_sim_irk_tab(ihm2mpc_handle *h, int M_sim)
+{
+    if (h->cfg.sim_integrator_type == IHM2MPC_INTEG_ERK) return 1;
+    if (h->sim_irk_tab && h->sim_irk_M == M_sim) return 0;
+    const IrkTab tab = make_tab(h->cfg.sim_integrator_type, h->cfg.dt / M_sim);
+    if (!h->sim_irk_tab && hipMalloc(&h->sim_irk_tab, sizeof(IrkTab)) != hipSuccess) return 1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return 1;          // a launch in flight may still read the old tableau
+    if (hipMemcpy(h->sim_irk_tab, &tab, sizeof(IrkTab), hipMemcpyHostToDevice) != hipSuccess) return 1;
+    h->sim_irk_M = M_sim;
+    return 0;
 }
 
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)

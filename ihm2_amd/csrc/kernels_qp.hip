@@ -943,6 +943,27 @@ __device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, i
     dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
 }
 
+// the plant by collocation: every quad of the wave integrates the instance's control period (same arithmetic in all sixteen: the DPP
+// exchanges want whole quads), lane 0 stores the new state -- the body of k_sim_irk (kernels_irk.hip)
+__device__ __noinline__ void call_sim_irk(const IrkTab *tab, int b, int model, int M, int nknots, const double *s_ref, const double *kappa_ref,
+                                          const int32_t *track_id, const double *u0, double *x0)
+{
+    const int st = threadIdx.x & 3;
+    double x[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) x[a] = x0[(size_t)b * 8 + a];
+    const double u_T = u0[(size_t)b * 2], u_d = u0[(size_t)b * 2 + 1];
+    const int tid = track_id[b];
+    TrackSeg trk;
+    trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
+    const IrkRows rows = irk_rows_from(tab, st);
+    irk_sim_quad(st, rows, model, M, x, u_T, u_d, trk);
+    __syncthreads();            // every lane has read the old state
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int a = 0; a < 8; a++) x0[(size_t)b * 8 + a] = x[a];
+}
+
 __device__ __noinline__ void call_line_search_fkin6(const LsArgs &ls, int b, int it, int last)
 {
     line_search_body<IHM2MPC_MODEL_FKIN6>(ls, b, it, last);
@@ -963,6 +984,7 @@ struct StepArgs {
     double *hist_u0, *hist_x0;              // (n_steps,B,2), (n_steps,B,8) or nullptr
     int32_t *hist_st, *hist_it;             // (n_steps,B) or nullptr
     const IrkTab *irk_tab;                  // IRK = 1: the tableau of the shooting intervals' collocation step, in device memory
+    const IrkTab *sim_irk_tab;              // plant steps by collocation (python/main.py:395-400: Radau IIA x M_sim) instead of RK4 x M_sim; nullptr: RK4
 };
 
 // SQP = 0: one RTI iteration per step (the SQP code is compiled out: next to the QP body it changed the register allocation of
@@ -1004,10 +1026,12 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
         const double x_old = (lane < 8) ? s.x0[(size_t)b * 8 + lane] : 0.0;
         // The kinematic plant (model 0) is one more "interval" of the linearisation -- lane N integrates (x0, u0) with the
         // code of the interval lanes, in lockstep with them -- so it costs no time; the dynamic plants take a phase of their own.
-        const bool kin_plant = !IRK && s.model == IHM2MPC_MODEL_FKIN6;
+        const bool irk_plant = s.sim_irk_tab != nullptr;
+        const bool kin_plant = !IRK && !irk_plant && s.model == IHM2MPC_MODEL_FKIN6;
         double *spare = s.lin + (size_t)B * N * LIN_REC;
         if (!kin_plant && act) {
-            if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
+            if (irk_plant) call_sim_irk(s.sim_irk_tab, b, s.model, s.M_sim, s.nknots, s.s_ref, s.kappa_ref, a.track_id, a.u0, s.x0);
+            else if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
             __syncthreads();
         }
         dev_prepare(b, lane, N, s.s_target, 2, s.x0, a.x, a.u, s.yref, s.yref_e);      // warm-start shift
@@ -1120,14 +1144,14 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
 #endif
 {
     if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return 1;
-    if (h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK) return 1;      // the loop's plant integrates with RK4
-    const bool irk = h->cfg.integrator_type != IHM2MPC_INTEG_ERK;       // collocation step on the shooting intervals: all-hard, batch-shared tables only
+    const bool irk_plant = h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK;     // the plants by collocation (python/main.py:395-400: Radau IIA x M_sim)
+    if (irk_plant && ihm2_upload_sim_irk_tab(h, M_sim)) return 1;
+    const bool irk = h->cfg.integrator_type != IHM2MPC_INTEG_ERK;       // collocation step on the shooting intervals: batch-shared tables only
     if (irk && !(h->irk_tab && h->uniform_H && h->uniform_CD && (h->cfg.nlp_solver_type != IHM2MPC_SQP || !h->sqp_globalization || h->ls_phi))) return 1;
     const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
     if (sqp && !h->ls_x) return 1;        // the caller allocates the line-search buffers first
     const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8;
 #if QP_SET == 0
-    if (!hard && irk) return 1;
     if (!hard) return ihm2_launch_steps_soft(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
 #else
     if (hard) return 1;
@@ -1144,6 +1168,7 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     s.active = (freeze || h->active_set) ? h->active : nullptr;
     s.hist_u0 = hist_u0; s.hist_x0 = hist_x0; s.hist_st = hist_st; s.hist_it = hist_it;
     s.irk_tab = (const IrkTab *)h->irk_tab;
+    s.sim_irk_tab = irk_plant ? (const IrkTab *)h->sim_irk_tab : nullptr;
     // every field of s is set: upload it (and the line search's block in the SQP mode)
     static_assert(sizeof(StepArgs) <= 32 * sizeof(double), "step_args holds 256 bytes");
     static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
@@ -1189,7 +1214,17 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them)
     if (!uni) return 1;
     const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
-#define LAUNCH_STEPS(NS_, NO_, PT_) do { if (sqp) LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 1); else LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 0); } while (0)
+#define LAUNCH_STEPS_IRK1(NS_, NO_, PT_, SQ_)                                                                                          \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute((const void *)k_steps<NS_, NO_, PT_, 1, SQ_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_steps<NS_, NO_, PT_, 1, SQ_, 1>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                     \
+    } while (0)
+#define LAUNCH_STEPS(NS_, NO_, PT_)                                                                                                     \
+    do {                                                                                                                                \
+        if (irk) { if (sqp) LAUNCH_STEPS_IRK1(NS_, NO_, PT_, 1); else LAUNCH_STEPS_IRK1(NS_, NO_, PT_, 0); }                            \
+        else if (sqp) LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 1);                                                                              \
+        else LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 0);                                                                                       \
+    } while (0)
     if (!h->path_on) {
         if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 0);
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0);
@@ -1201,6 +1236,7 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
         else return 1;
     }
 #undef LAUNCH_STEPS
+#undef LAUNCH_STEPS_IRK1
 #endif
 #undef LAUNCH_STEPS_1
     return 0;

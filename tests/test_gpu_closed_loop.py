@@ -355,3 +355,71 @@ def test_block_qp_kernel_matches_the_single_wave_kernel_and_the_oracle(track, B,
         assert np.mean(sa == sb_) >= 0.98 and np.mean(ia == ib) >= 0.9
         ok = (sa == 0) & (sb_ == 0)
         assert np.max(np.abs(ua[ok] - ub[ok]) / np.maximum(1.0, np.abs(ub[ok]))) < 1e-5      # closed loop: rounding differences are fed back for six steps
+
+
+RADAU_PLANT = dict(sim_integrator_type="IRK", sim_collocation_type="GAUSS_RADAU_IIA")                 # python/main.py:395-400
+
+
+def _soft_track_ocp(track, **opts):
+    """configs[2]-style soft nonlinear track rows (old/generate_acaods_interface.py:191-212,380-449) on the fkin6 OCP."""
+    ocp = make_ocp(**opts)
+    ocp.model.con_h_expr = "track"
+    c = ocp.constraints
+    c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
+    c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
+    ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+    ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
+    return ocp, np.array([[track.right_widths.min(), track.left_widths.min()]])
+
+
+@pytest.mark.parametrize("name,plant,soft,opts", [
+    ("irk_soft_rows", 0, True, IRK),                                        # collocation on the intervals + soft track-row tables
+    ("live_soft_rows", -2, True, {**LIVE, **IRK}),                          # the live options on the soft track-row tables
+    ("radau_plant", -2, False, RADAU_PLANT),                                # RK4 intervals, the plants by Radau IIA inside the loop
+    ("live_options_live_plant", -1, False, {**LIVE, **IRK, **RADAU_PLANT}),  # python/main.py:227-238 + :395-400 in ONE launch
+])
+def test_persistent_loop_with_collocation_soft_tables_and_radau_plants(track, name, plant, soft, opts, monkeypatch):
+    """the persistent loop takes the collocation integrator with the soft / track-row constraint tables, and plants
+    integrated by Radau IIA x M_sim -- so the reference's live solver options (python/main.py:227-238) with its live plant integrator
+    (:395-400) run as one launch.  freeze=True proves the persistent kernel exists for the configuration (the call refuses to fall back);
+    the results are bit-identical to the same number of ihm2mpc_step calls."""
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    monkeypatch.setenv("IHM2MPC_BLOCK_QP", "0")
+    B, steps, M_sim = 70, 8, 30
+    x0 = sample_x0(track, B, seed=57)
+
+    def make():
+        if soft:
+            ocp, widths = _soft_track_ocp(track, **opts)
+            s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref, track_widths=widths)
+        else:
+            s = BatchedOcpSolver(make_ocp(**opts), B, track.s_ref, track.kappa_ref)
+        s.set_lap_wrap(True); s.set_x0(x0); s.init_guess()
+        s.step(40.0, model=plant, M_sim=M_sim)
+        return s
+
+    probe = make()
+    probe.run_steps(40.0, 2, model=plant, M_sim=M_sim, freeze=True, status_hist=True)        # raises if there is no persistent kernel for this
+    probe.free()
+    res = []
+    for persistent in (False, True):
+        s = make()
+        if persistent:
+            h = s.run_steps(40.0, steps, model=plant, M_sim=M_sim, u0_hist=True, x0_hist=True, status_hist=True, qp_iter_hist=True)
+        else:
+            h = dict(u0=[], x0=[], status=[], qp_iter=[])
+            for _ in range(steps):
+                s.step(40.0, model=plant, M_sim=M_sim)
+                h["u0"].append(s.get_u0()); h["x0"].append(s.get_x0()); h["status"].append(s.get_status()); h["qp_iter"].append(s.get_qp_iter())
+            h = {k: np.array(v) for k, v in h.items()}
+        res.append((h, s.get_x(), s.get_u(), s.get_multipliers()))
+        s.free()
+    (ha, xa, ua, ma), (hb, xb, ub, mb) = res
+    for k in ("status", "qp_iter", "x0", "u0"):
+        np.testing.assert_array_equal(ha[k], hb[k], err_msg=f"{name}: {k}")
+    np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
+    np.testing.assert_array_equal(ma[0], mb[0]); np.testing.assert_array_equal(ma[1], mb[1])
+    good = (0, 2) if "nlp_solver_type" in opts else (0,)
+    assert np.isin(ha["status"], good).mean() > 0.8
+    assert np.all(np.isfinite(ha["x0"])) and np.all(ha["x0"][-1, :, 0] != x0[:, 0])          # the plants moved
