@@ -11,6 +11,8 @@
 // Sensitivities are held column-wise in registers; only the structurally non-zero entries of the
 // 8x10 matrix are stored (52 for fkin6, 55 for fdyn6) and only the non-zeros of the model Jacobian (31 / 37) are multiplied
 // (model.hpp: JX_MASK / S_COL_MASK).  Algorithmic traffic per pair: read 10 + 8 doubles, write 88.
+#include <cstdlib>
+
 #include "ihm2mpc_internal.h"
 #include "model.hpp"
 #include "device_steps.hpp"
@@ -217,13 +219,16 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
     if (h->cfg.integrator_type != IHM2MPC_INTEG_ERK) { ihm2_launch_linearize_irk(h); return; }
     const long total = (long)h->B * h->N;
     const int blocks = (int)((total + 63) / 64);
+    // diagnostic (tools/bench_linearize.py --cols): the column-parallel kernel -- one sensitivity column per wavefront, ten wavefronts
+    // per block of 64 intervals -- at any batch size, to measure it against the lane-per-interval kernel
+    static const bool force_cols = getenv("IHM2MPC_LINEARIZE_COLS") && getenv("IHM2MPC_LINEARIZE_COLS")[0] == '1';
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U)
         hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
         hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
-    else if (blocks <= 2)      // one or a few real-time controllers: the latency path (not bit-identical to the batch kernel, see above)
+    else if (blocks <= 2 || force_cols)      // one or a few real-time controllers: the latency path (not bit-identical to the batch kernel, see above)
         hipLaunchKernelGGL(k_linearize_cols, dim3(blocks, 10), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else

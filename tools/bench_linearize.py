@@ -10,7 +10,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="fdyn6u"); ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--lib", default=None); ap.add_argument("--integrator", default="ERK"); ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--check", type=int, default=64)
+ap.add_argument("--cols", action="store_true", help="fkin6 / ERK: the column-parallel kernel (one sensitivity column per wavefront) at this batch size")
 args = ap.parse_args()
+if args.cols: os.environ["IHM2MPC_LINEARIZE_COLS"] = "1"
 from ihm2_amd import _lib
 if args.lib: _lib.LIB_PATH = os.path.abspath(args.lib)
 from conftest import make_ocp, sample_x0
@@ -29,7 +31,7 @@ t0 = time.perf_counter()
 for _ in range(args.reps): s.linearize()
 s.synchronize()
 ms = (time.perf_counter() - t0) / args.reps * 1e3
-out = {"model": args.model, "batch": args.batch, "integrator": args.integrator, "linearize_ms": ms}
+out = {"model": args.model, "batch": args.batch, "integrator": args.integrator, "column_parallel": bool(args.cols), "linearize_ms": ms}
 if args.check:
     from oracle import oracle as orc
     P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
