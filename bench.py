@@ -91,7 +91,7 @@ def flops_per_solve(n_ipm):
 
 # --------------------------------------------------------------------------------------------------------------- workloads beyond the headline
 def rti_throughput(model, B, steps=20, warmup=5, tracks=(TRACK,), terminal_bounds="reference", track_rows=None, recover=False, host_state=False,
-                   sqp=None, persistent=False, integrator="ERK", device=0, x0=None, track_id=None, ranks=None):
+                   sqp=None, persistent=False, integrator="ERK", device=0, x0=None, track_id=None, ranks=None, plant_integrator="ERK"):
     """Closed-loop RTI throughput of one batch on one device (the workloads of BASELINE.json configs[1..3] and their variants).
     ``x0`` / ``track_id``: this rank's rows of a global batch (default: the per-track draws of :func:`monte_carlo_batch`).
     ``ranks``: a RankContext -- the timed region is then bracketed by its barrier."""
@@ -106,6 +106,8 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=(TRACK,), terminal_bound
     ocp.solver_options.tf = 2.0
     if integrator == "IRK":     # python/main.py:234-236: IRK, 4 Gauss-Legendre stages, one step per shooting interval
         ocp.solver_options.integrator_type, ocp.solver_options.sim_method_num_steps = "IRK", 1
+    if plant_integrator == "IRK":     # python/main.py:395-400: the plants by IRK, GAUSS_RADAU_IIA, 4 stages (x M_sim steps)
+        ocp.solver_options.sim_integrator_type, ocp.solver_options.sim_collocation_type = "IRK", "GAUSS_RADAU_IIA"
     if sqp is not None:         # the live options of python/main.py:230-237: "SQP", max_iter 2, "MERIT_BACKTRACKING"
         ocp.solver_options.nlp_solver_type, ocp.solver_options.nlp_solver_max_iter, ocp.solver_options.globalization = "SQP", 2, sqp
     if terminal_bounds == "stage":      # see IHM2Controller(terminal_bounds=...): quirk Q1
@@ -168,7 +170,7 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=(TRACK,), terminal_bound
     solver.synchronize(); el = time.perf_counter() - t0
     st = solver.get_status()
     out = dict(model=model, B=B, tracks=len(plans), terminal_bounds=terminal_bounds, track_rows=track_rows, recover=recover, host_state=host_state, sqp=sqp,
-               persistent=persistent, integrator=integrator, steps=steps, elapsed_s=el, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
+               persistent=persistent, integrator=integrator, plant_integrator=plant_integrator, steps=steps, elapsed_s=el, solves_per_s=B * steps / el, ms_per_step=el / steps * 1e3, linearize_ms=tl / steps,
                qp_ms=tq / steps, ok_fraction=n_ok / (B * steps), n_ok=n_ok, status={str(k): int(v) for k, v in enumerate(np.bincount(st, minlength=5)) if v},
                qp_iter_mean=float(solver.get_qp_iter().mean()))
     if sqp:

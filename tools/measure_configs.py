@@ -48,6 +48,12 @@ if __name__ == "__main__":
                    (rti_throughput, dict(model="fkin6", B=1024, integrator="IRK", persistent=True, steps=500, warmup=20)),
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", integrator="IRK", persistent=True, steps=500, warmup=20)),
                    (rti_throughput, dict(model="fkin6", B=1024, sqp="FIXED_STEP", integrator="IRK", persistent=True, steps=500, warmup=20)),
+                   # round 3: the persistent loop on the soft track-row tables with the collocation integrator, and with the plants by Radau IIA --
+                   # the live options (python/main.py:227-238) with the live plant integrator (:395-400) in one launch
+                   (rti_throughput, dict(model="fkin6", B=1024, track_rows="soft", integrator="IRK", persistent=True, steps=200, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, plant_integrator="IRK", persistent=True, steps=200, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", integrator="IRK", plant_integrator="IRK", persistent=True, steps=200, warmup=20)),
+                   (rti_throughput, dict(model="fkin6", B=1024, sqp="MERIT_BACKTRACKING", integrator="IRK", plant_integrator="IRK", persistent=False, steps=20, warmup=5)),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U")),
                    (closed_loop_config5, dict(B=4096, steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0))),
                    (closed_loop_config5, dict(B=4096, steps=200, device_loop=True)),
