@@ -56,6 +56,55 @@ def test_persistent_loop_matches_oracle_loop(track):
     assert _rel(s.get_x(), x) < 1e-6 and _rel(s.get_u(), u) < 1e-6
 
 
+def test_long_closed_loop_stays_with_the_oracle(track):
+    """Drift check over the length of a bench run and beyond: 150 control steps (7.5 s of driving, lap wrap included) of 48 instances in
+    persistent launches of 25 steps, against the oracle loop.  Measured (tools/dbg_drift.py): controls and plant states agree to 1e-9 all
+    along, except where a marginal convergence test falls the other way on one side -- visibly (an iteration count that differs) or not (the
+    followed residuals pass and their check against the data does or does not, so the last Newton step takes the residuals from another
+    source): the two controls are then one interior-point tolerance apart (3e-5 observed; 3e-4 rad is the solver's accuracy at tol 1e-6 of
+    the gradient scale) for ONE step and the stable closed loop is back at 1e-9 two steps later.  Asserted: at least
+    99 % of the (instance, step) pairs within 1e-6 relative (north star: 1e-5), every pair within 3e-4, statuses equal, no drift at the end."""
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import oracle as orc
+
+    B, M_sim, L = 48, 25, track.lap_length
+    ocp = make_ocp()
+    s = BatchedOcpSolver(ocp, B, track.s_ref, track.kappa_ref)
+    P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, B, seed=77)
+    s.set_x0(x0); s.init_guess(); s.set_lap_wrap(True)
+    x, u = s.get_x(), s.get_u()
+    s.prepare_step(40.0); st = s.solve()
+    yref, yref_e = orc.prepare_step(N, x0, 40.0, x, u)
+    out = P.rti_step(x, u, x0, yref, yref_e)
+    np.testing.assert_array_equal(st, out["status"])
+    pi, lam = out["pi"], out["lam"]
+    xc = x0.copy()
+    same_iters = total = close = 0
+    good = np.ones(B, dtype=bool)          # instances that have solved every step so far
+    dev = lambda a, b: np.max(np.abs(a - b) / (1.0 + np.abs(b)), axis=-1)
+    for chunk in range(6):
+        h = s.run_steps(40.0, 25, model=0, M_sim=M_sim, u0_hist=True, x0_hist=True, status_hist=True, qp_iter_hist=True)
+        for i in range(25):
+            w = xc[:, 0] >= L                                # ihm2mpc_set_lap_wrap: a car past the lap is moved back by one lap, iterate included
+            xc[w, 0] -= L; x[w, :, 0] -= L
+            xc = P.sim_step(xc, u[:, 0].copy(), 0, M_sim)
+            yref, yref_e = orc.prepare_step(N, xc, 40.0, x, u)
+            out = P.rti_step(x, u, xc, yref, yref_e, pi=pi, lam=lam)
+            pi, lam = out["pi"], out["lam"]
+            # a QP that diverges ends as NaN (1) on the GPU and as failed (4) in the oracle (DESIGN.md section 2): both mean "no step";
+            # such an instance keeps its iterate on both sides and is left out from then on
+            np.testing.assert_array_equal(h["status"][i] == 0, out["status"] == 0)
+            good &= out["status"] == 0
+            d = np.maximum(dev(h["u0"][i], u[:, 0]), dev(h["x0"][i], xc))[good]
+            assert np.all(d < 3e-4), (chunk, i, float(d.max()))
+            close += int(np.sum(d < 1e-6)); total += int(good.sum())
+            same_iters += int(np.sum((h["qp_iter"][i] == out["qp_iter"])[good]))
+    assert close >= 0.99 * total and same_iters >= 0.97 * total and good.sum() >= B - 2
+    assert _rel(s.get_x()[good], x[good]) < 1e-6 and _rel(s.get_u()[good], u[good]) < 1e-6          # no drift left at the end
+    assert np.any(xc[:, 0] < x0[:, 0])          # somebody completed the lap and was wrapped
+
+
 def _accepted_tracks():
     """Every data/ track the table builder takes (three of the seven are open paths)."""
     from ihm2_amd.track import track_table
