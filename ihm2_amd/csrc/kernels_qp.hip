@@ -620,11 +620,15 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 stream_rows<-1, 8, 4>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
                     [&](int k, bool odd, double &prb, double &base) { prb = Prb[k * 8 + (odd ? g : w)]; base = pv[k * 8 + (odd ? w : g)]; },
                     [&](int k, double m, bool odd, double prb, double base) {
+                        // only the product with the carried value sits on the dependent chain: m * prb and the stage's base term (added
+                        // by ONE lane of each sum) are formed as soon as the operands arrive
                         if (!odd) {
-                            pg = base + sum8(m * (prb + pw));
+                            const double off = fma(m, prb, (w == 0) ? base : 0.0);
+                            pg = sum8(fma(m, pw, off));
                             if (w == 0) pv[k * 8 + g] = pg;
                         } else {
-                            pw = base + sum_stride8(m * (prb + pg));
+                            const double off = fma(m, prb, (g == 0) ? base : 0.0);
+                            pw = sum_stride8(fma(m, pg, off));
                             if (g == 0) pv[k * 8 + w] = pw;
                         }
                     });
@@ -665,11 +669,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 stream_rows<+1, 8, 4>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
                     [&](int k, bool odd, double &c, double &unused) { c = dz[(k + 1) * 10 + (odd ? w : g)]; unused = 0.0; },
                     [&](int k, double m, bool odd, double c, double) {
+                        // the affine term rides in ONE lane's product (an fma off the dependent chain's critical add)
                         if (!odd) {
-                            dxg = c + sum8(m * dxw);
+                            dxg = sum8(fma(m, dxw, (w == 0) ? c : 0.0));
                             if (w == 0) dz[(k + 1) * 10 + g] = dxg;
                         } else {
-                            dxw = c + sum_stride8(m * dxg);
+                            dxw = sum_stride8(fma(m, dxg, (g == 0) ? c : 0.0));
                             if (g == 0) dz[(k + 1) * 10 + w] = dxw;
                         }
                     });

@@ -55,10 +55,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    // every lane of these permutations has an in-range source, so the "old" operand is never used: passing the value itself
-    // saves the two zero-initialising moves a constant would cost per step
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // every lane of these permutations has an in-range source, so the "old" operand is never used: the mov_dpp form leaves it undefined,
+    // which saves the two register copies per move that a tied old = source costs (v_mov_b32_dpp writes a fresh register)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane)
