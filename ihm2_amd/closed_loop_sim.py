@@ -49,9 +49,13 @@ _CART_CODE = {SimModelVariant.CART_KIN6: 3, SimModelVariant.CART_DYN6: 4, SimMod
 
 @dataclass
 class SimulatorConfig:
+    """``new_python/simulator.py:25-40`` (sic ``colloaction_type``).  ``integrator_type``: ``None`` = whatever the controller's device state
+    was created with (``IHM2Controller(sim_integrator_type=...)``: "ERK" = RK4 x num_steps, "IRK" = Radau IIA x num_steps as
+    ``python/main.py:395-400``); a value is checked against it."""
+
     sampling_time: float
-    integrator_type: str = "ERK"
-    colloaction_type: str = "GAUSS_RADAU_IIA"      # accepted for drop-in; the device plant is RK4 x num_steps
+    integrator_type: str | None = None
+    colloaction_type: str = "GAUSS_RADAU_IIA"
     num_steps: int = 100
 
 
@@ -61,6 +65,10 @@ class Simulator:
     def __init__(self, controller: IHM2Controller, config: SimulatorConfig, variant: SimModelVariant = SimModelVariant.KIN6_DYN6):
         if variant not in _PLANT_CODE:
             raise NotImplementedError(f"plant variant {variant.name}")
+        have = controller.solver.ocp.solver_options.sim_integrator_type
+        if config.integrator_type is not None and config.integrator_type != have:
+            raise ValueError(f'SimulatorConfig.integrator_type = {config.integrator_type!r}, but the controller\'s device state integrates its plants with '
+                             f'{have!r}: create the controller with sim_integrator_type={config.integrator_type!r}')
         self.controller, self.config, self.variant = controller, config, variant
 
     def simulate(self, x: np.ndarray, u: np.ndarray) -> np.ndarray:

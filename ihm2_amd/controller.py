@@ -102,6 +102,8 @@ class IHM2Controller(Controller):
         track_id=None,
         device: int = 0,
         sim_method_num_steps: int = 25,
+        integrator_type: str = "ERK",
+        sim_integrator_type: str = "ERK",
         nlp_solver_type: str = "SQP_RTI",
         nlp_solver_max_iter: int = 1,
         globalization: str = "FIXED_STEP",
@@ -166,6 +168,10 @@ class IHM2Controller(Controller):
         opts.globalization = globalization              # python/main.py:237 asks "MERIT_BACKTRACKING" of its "SQP" solver
         opts.nlp_tol = nlp_tol
         opts.sim_method_num_steps = sim_method_num_steps
+        # python/main.py:234-236: "IRK" = 4 Gauss-Legendre stages (acados' default collocation), sim_method_num_steps per interval;
+        # sim_integrator_type: the plant steps behind this controller's device state (python/main.py:395-400: "IRK", GAUSS_RADAU_IIA)
+        opts.integrator_type = integrator_type
+        opts.sim_integrator_type, opts.sim_collocation_type = sim_integrator_type, "GAUSS_RADAU_IIA"
         ocp.solver_options = opts
         ocp.cost.W, ocp.cost.W_e = default_weights(q_s, q_n, q_psi, q_v_x, q_v_y, q_r, q_T, q_delta, q_s_f, q_n_f, q_psi_f,
                                                    q_v_x_f, q_v_y_f, q_r_f, q_T_f, q_delta_f, q_T_dot, q_delta_dot)
@@ -178,6 +184,16 @@ class IHM2Controller(Controller):
         self.solver.set_x(x_pred)
         self.solver.set_u(u_pred)
         self.last_status = np.zeros(self.B, dtype=np.int32)
+
+    @classmethod
+    def with_live_options(cls, s_ref, kappa_ref, *args, **kw) -> "IHM2Controller":
+        """The controller exactly as the reference configures its solver (``python/main.py:227-238``): SQP with two iterations,
+        MERIT_BACKTRACKING, IRK with four Gauss-Legendre stages and one step per shooting interval -- and its plants by Radau IIA
+        (``:395-400``) unless ``sim_integrator_type`` says otherwise.  (The default constructor is the metric's SQP_RTI + RK4 x 25.)"""
+        live = dict(nlp_solver_type="SQP", nlp_solver_max_iter=2, globalization="MERIT_BACKTRACKING", integrator_type="IRK",
+                    sim_method_num_steps=1, sim_integrator_type="IRK")
+        live.update(kw)
+        return cls(s_ref, kappa_ref, *args, **live)
 
     # -- predictions of the last solve (python/main.py:331-332) --
     @property

@@ -423,3 +423,34 @@ def test_persistent_loop_with_collocation_soft_tables_and_radau_plants(track, na
     good = (0, 2) if "nlp_solver_type" in opts else (0,)
     assert np.isin(ha["status"], good).mean() > 0.8
     assert np.all(np.isfinite(ha["x0"])) and np.all(ha["x0"][-1, :, 0] != x0[:, 0])          # the plants moved
+
+
+def test_mil_loop_as_the_reference_configures_it(track, monkeypatch):
+    """The whole reference configuration through the new_python-shaped surface: IHM2Controller.with_live_options (python/main.py:227-238: SQP x 2,
+    MERIT_BACKTRACKING, IRK GL4 x 1) + Simulator with the Radau IIA plants (:395-400, KIN6_DYN6 switch :482-489 on the un-crossed model) --
+    host loop, device loop and the one-launch persistent loop give the same cars."""
+    monkeypatch.setenv("IHM2MPC_BLOCK_QP", "0")
+    from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop_device, run_closed_loop_persistent
+    from ihm2_amd.controller import IHM2Controller
+
+    B, steps = 24, 20
+    x0 = sample_x0(track, B, seed=23)
+    out = []
+    for runner in (run_closed_loop_device, run_closed_loop_persistent):
+        # (stage terminal box and soft plant-state bounds as in the configs[4] runs: with hard boxes the dynamic plant carries some cars across
+        # n = n_max, where the kinematic controller's QP is infeasible)
+        ctrl = IHM2Controller.with_live_options(track.s_ref, track.kappa_ref, batch_size=B, terminal_bounds="stage", soft_state_bounds=(1000.0, 1000.0))
+        assert ctrl.solver.ocp.solver_options.integrator_type == "IRK" and ctrl.solver.ocp.solver_options.nlp_solver_max_iter == 2
+        sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, integrator_type="IRK", num_steps=50), SimModelVariant.KIN6_DYN6U)
+        ctrl.warm_start(x0)
+        out.append(runner(ctrl, sim, x0, steps, lap_length=track.lap_length))
+        ctrl.solver.free()
+    d, p = out
+    np.testing.assert_array_equal(d.x, p.x); np.testing.assert_array_equal(d.u, p.u); np.testing.assert_array_equal(d.status, p.status)
+    assert np.isin(d.status, (0, 2)).mean() > 0.9 and d.alive.sum() >= B - 4
+    assert np.all(d.x[-1, d.alive, 0] > x0[d.alive, 0] + 3.0)
+    # a Simulator that asks for another plant integrator than the controller's device state has is refused
+    ctrl = IHM2Controller(track.s_ref, track.kappa_ref, batch_size=2)
+    with pytest.raises(ValueError, match="sim_integrator_type"):
+        Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, integrator_type="IRK"), SimModelVariant.KIN6)
+    ctrl.solver.free()
