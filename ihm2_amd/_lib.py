@@ -47,6 +47,7 @@ SYMBOLS = {
     "ihm2mpc_get_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "ihm2mpc_set_tracks": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_build_tracks": (C.c_int, [_H, C.c_int32, c_int32_p, c_double_p, c_double_p]),
+    "ihm2mpc_fit_tracks": (C.c_int, [_H, C.c_int32, c_int32_p, c_double_p, C.c_double, c_double_p, c_double_p]),
     "ihm2mpc_get_tracks": (C.c_int, [_H] + [c_double_p] * 5),
     "ihm2mpc_set_track_id": (C.c_int, [_H, c_int32_p]),
     "ihm2mpc_set_weights": (C.c_int, [_H, c_double_p, c_double_p]),

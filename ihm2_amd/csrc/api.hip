@@ -273,6 +273,41 @@ int ihm2mpc_build_tracks(ihm2mpc_handle *h, int32_t max_seg, const int32_t *nseg
     return 0;
 }
 
+int ihm2mpc_fit_tracks(ihm2mpc_handle *h, int32_t max_pts, const int32_t *npts, const double *xy, double curv_weight, double *coeffs_X, double *coeffs_Y)
+{
+    CHECK_H(h);
+    if (!npts || !xy || !coeffs_X || !coeffs_Y) return fail("null argument");
+    if (!(curv_weight >= 0.0)) return fail("curv_weight must be >= 0");
+    if (max_pts < 3 || 7 * max_pts + 2 > 1280) return fail("max_pts must be in 3 .. 182 (the elimination lists the non-zeros of a row in LDS)");
+    const int nt = h->cfg.ntracks;
+    for (int t = 0; t < nt; t++)
+        if (npts[t] < 3 || npts[t] > max_pts) return fail("track %d has %d centre-line points (3 .. max_pts = %d)", t, npts[t], max_pts);
+    const size_t m = 7 * (size_t)max_pts, nwork = (size_t)nt * m * (m + 2), nxy = (size_t)nt * max_pts * 2, nc = (size_t)nt * max_pts * 4;
+    double *dev = nullptr;
+    int32_t *di = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, (nwork + nxy + 2 * nc) * sizeof(double)));
+    if (hipMalloc((void **)&di, 2 * (size_t)nt * sizeof(int32_t)) != hipSuccess) { (void)hipFree(dev); return fail("out of device memory"); }
+    double *work = dev, *dxy = dev + nwork, *cX = dxy + nxy, *cY = cX + nc;
+    std::vector<int32_t> flags(nt, 1);
+    int rc = 0;
+    if (hipMemcpyAsync(dxy, xy, nxy * sizeof(double), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemcpyAsync(di, npts, nt * sizeof(int32_t), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+        hipMemsetAsync(cX, 0, 2 * nc * sizeof(double), h->stream) != hipSuccess) rc = fail("upload of the centre lines failed");
+    if (!rc) {
+        ihm2_launch_track_fit(h, max_pts, di, dxy, curv_weight, work, cX, cY, di + nt);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(coeffs_X, cX, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipMemcpyAsync(coeffs_Y, cY, nc * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipMemcpyAsync(flags.data(), di + nt, nt * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) rc = fail("spline-fit kernel failed");
+    }
+    (void)hipFree(dev); (void)hipFree(di);
+    if (rc) return rc;
+    for (int t = 0; t < nt; t++)
+        if (flags[t]) return fail("the spline fit of track %d is singular (coincident centre-line points?)", t);
+    return 0;
+}
+
 int ihm2mpc_get_tracks(ihm2mpc_handle *h, double *s_ref, double *kappa_ref, double *X_ref, double *Y_ref, double *phi_ref)
 {
     CHECK_H(h);

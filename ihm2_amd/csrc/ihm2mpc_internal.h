@@ -131,6 +131,8 @@ struct ihm2mpc_handle {
 // mode: bit 0 = reference ramp (needs x0), bit 1 = warm-start shift
 void ihm2_launch_prepare(ihm2mpc_handle *h, double s_target, int mode, hipStream_t stream);
 void ihm2_launch_build_tracks(ihm2mpc_handle *h, int max_seg, const int32_t *nseg, const double *cX, const double *cY, double *work);
+void ihm2_launch_track_fit(ihm2mpc_handle *h, int max_pts, const int32_t *npts, const double *xy, double curv_weight, double *work, double *cX, double *cY,
+                           int32_t *fail_flag);
 void ihm2_launch_sim_dyn10(ihm2mpc_handle *h, int M, const double *x, const double *u, double *xn, hipStream_t stream);
 void ihm2_launch_sim_dyn10_irk(ihm2mpc_handle *h, int integ, int M, int newton_iter, const double *x, const double *u, double *xn, hipStream_t stream);
 void ihm2_launch_wrap_lap(ihm2mpc_handle *h);

@@ -181,6 +181,114 @@ __global__ __launch_bounds__(64) void k_sim_dyn10(int B, int M, double dt, int n
     for (int i = 0; i < 15; i++) xn[(size_t)b * 15 + i] = x[i];
 }
 
+// ---- closed cubic-spline fit of a centre line (python/motion_planning.py:28-124), one workgroup per track ----
+// The reference hands  min 1/2 p'P p + q'p  s.t.  A p = 0  (P = B'B + w C'C + 1e-10 I: interpolation error + curvature, :88-101; A: value, first
+// and second derivative continuity between consecutive segments of the CLOSED path, :59-87) to qpsolvers / proxqp.  It is one linear system:
+// the KKT matrix [[P, A'], [A, 0]] (7n x 7n for n points, cyclic-banded) with the right-hand sides (-q_x, 0), (-q_y, 0).  Solved here by
+// Gaussian elimination with partial pivoting on the augmented matrix in global memory (row-major, m + 2 columns): per pivot the rows and the
+// columns that are non-zero are listed in LDS first -- the matrix stays sparse under elimination, so a step touches tens of entries, not m^2.
+constexpr int FIT_T = 256, FIT_LIST = 1280;
+__global__ __launch_bounds__(FIT_T) void k_track_fit(int max_pts, const int32_t *__restrict__ npts, const double *__restrict__ xy, double curv_weight,
+                                                     double *__restrict__ work, double *__restrict__ cX, double *__restrict__ cY, int32_t *__restrict__ fail_flag)
+{
+    __shared__ int rows[FIT_LIST], cols[FIT_LIST], n_rows, n_cols;
+    __shared__ double red_v[FIT_T];
+    __shared__ int red_i[FIT_T];
+    const int trk = blockIdx.x, tid = threadIdx.x;
+    const int n = npts[trk], m = 7 * n, ld = m + 2;
+    const double *pts = xy + (size_t)trk * max_pts * 2;
+    double *Mx = work + (size_t)trk * (7 * (size_t)max_pts) * (7 * (size_t)max_pts + 2);
+    for (size_t e = tid; e < (size_t)m * ld; e += FIT_T) Mx[e] = 0.0;
+    __syncthreads();
+    for (int i = tid; i < n; i += FIT_T) {
+        const int nx = (i + 1) % n, pv = (i + n - 1) % n;
+        const double dsi = hypot(pts[nx * 2] - pts[i * 2], pts[nx * 2 + 1] - pts[i * 2 + 1]);             // chord i -> i + 1 (closing chord last)
+        const double dsn = hypot(pts[((nx + 1) % n) * 2] - pts[nx * 2], pts[((nx + 1) % n) * 2 + 1] - pts[nx * 2 + 1]);
+        const double rho = dsi / dsn;
+        // P block of segment i: B'B on c0, w C'C on (c2, c3), 1e-10 on the diagonal
+        const double w2 = 2.0 / (dsi * dsi), w3 = 6.0 / (dsi * dsi);
+        double *Pi = Mx + (size_t)(4 * i) * ld + 4 * i;
+        Pi[0] = 1.0 + 1e-10; Pi[ld + 1] = 1e-10;
+        Pi[2 * ld + 2] = curv_weight * w2 * w2 + 1e-10; Pi[2 * ld + 3] = curv_weight * w2 * w3;
+        Pi[3 * ld + 2] = curv_weight * w3 * w2;          Pi[3 * ld + 3] = curv_weight * w3 * w3 + 1e-10;
+        // continuity rows 3i .. 3i + 2 of A (and their transposes): segment i at t = 1 against segment i + 1 at t = 0
+        const double a[3][4] = {{1, 1, 1, 1}, {0, 1, 2, 3}, {0, 0, 2, 6}};
+        const double nb[3] = {-1.0, -rho, -2.0 * rho * rho};
+        for (int q = 0; q < 3; q++) {
+            const int r = 4 * n + 3 * i + q;
+            for (int c = 0; c < 4; c++)
+                if (a[q][c] != 0.0) { Mx[(size_t)r * ld + 4 * i + c] = a[q][c]; Mx[(size_t)(4 * i + c) * ld + r] = a[q][c]; }
+            // (n = 2 would put both junctions of a segment on the same coefficients: accumulate)
+            Mx[(size_t)r * ld + 4 * nx + q] += nb[q]; Mx[(size_t)(4 * nx + q) * ld + r] += nb[q];
+        }
+        (void)pv;
+        Mx[(size_t)(4 * i) * ld + m] = pts[i * 2];          // -q = B' path
+        Mx[(size_t)(4 * i) * ld + m + 1] = pts[i * 2 + 1];
+    }
+    __syncthreads();
+    bool singular = false;
+    for (int c = 0; c < m; c++) {
+        // pivot: the first row with the largest |entry| in column c
+        double bv = -1.0; int bi = c;
+        for (int r = c + tid; r < m; r += FIT_T) { const double v = fabs(Mx[(size_t)r * ld + c]); if (v > bv) { bv = v; bi = r; } }
+        red_v[tid] = bv; red_i[tid] = bi;
+        __syncthreads();
+        for (int off = FIT_T / 2; off > 0; off >>= 1) {
+            if (tid < off) {
+                const double ov = red_v[tid + off]; const int oi = red_i[tid + off];
+                if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const int p = red_i[0];
+        if (!(red_v[0] > 0.0)) { singular = true; break; }
+        if (tid == 0) { n_rows = 0; n_cols = 0; }
+        __syncthreads();
+        if (p != c)
+            for (int j = c + tid; j < ld; j += FIT_T) { const double t0 = Mx[(size_t)c * ld + j], t1 = Mx[(size_t)p * ld + j]; Mx[(size_t)c * ld + j] = t1; Mx[(size_t)p * ld + j] = t0; }
+        __syncthreads();
+        // non-zero columns of the pivot row (right of the pivot, right-hand sides included) and rows with a non-zero entry under the pivot
+        for (int j = c + 1 + tid; j < ld; j += FIT_T) if (Mx[(size_t)c * ld + j] != 0.0) { const int q = atomicAdd(&n_cols, 1); if (q < FIT_LIST) cols[q] = j; }
+        for (int r = c + 1 + tid; r < m; r += FIT_T) if (Mx[(size_t)r * ld + c] != 0.0) { const int q = atomicAdd(&n_rows, 1); if (q < FIT_LIST) rows[q] = r; }
+        __syncthreads();
+        const int nr = min(n_rows, FIT_LIST), nc = min(n_cols, FIT_LIST);      // (m + 2 <= FIT_LIST is checked on the host)
+        const double ipiv = 1.0 / Mx[(size_t)c * ld + c];
+        for (int e = tid; e < nr * nc; e += FIT_T) {
+            const int r = rows[e / nc], j = cols[e % nc];
+            Mx[(size_t)r * ld + j] -= Mx[(size_t)r * ld + c] * ipiv * Mx[(size_t)c * ld + j];
+        }
+        __syncthreads();
+    }
+    if (singular) { if (tid == 0) fail_flag[trk] = 1; return; }
+    // back substitution, both right-hand sides: x_c = (rhs_c - sum_{j > c} M_cj x_j) / M_cc; the solution overwrites the right-hand sides
+    for (int c = m - 1; c >= 0; c--) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = c + 1 + tid; j < m; j += FIT_T) {
+            const double v = Mx[(size_t)c * ld + j];
+            if (v != 0.0) { s0 = fma(v, Mx[(size_t)j * ld + m], s0); s1 = fma(v, Mx[(size_t)j * ld + m + 1], s1); }
+        }
+        red_v[tid] = s0;
+        __syncthreads();
+        for (int off = FIT_T / 2; off > 0; off >>= 1) { if (tid < off) red_v[tid] += red_v[tid + off]; __syncthreads(); }
+        const double t0 = red_v[0];
+        __syncthreads();
+        red_v[tid] = s1;
+        __syncthreads();
+        for (int off = FIT_T / 2; off > 0; off >>= 1) { if (tid < off) red_v[tid] += red_v[tid + off]; __syncthreads(); }
+        if (tid == 0) {
+            const double d = Mx[(size_t)c * ld + c];
+            Mx[(size_t)c * ld + m] = (Mx[(size_t)c * ld + m] - t0) / d;
+            Mx[(size_t)c * ld + m + 1] = (Mx[(size_t)c * ld + m + 1] - red_v[0]) / d;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 4 * n; e += FIT_T) {
+        cX[(size_t)trk * max_pts * 4 + e] = Mx[(size_t)e * ld + m];
+        cY[(size_t)trk * max_pts * 4 + e] = Mx[(size_t)e * ld + m + 1];
+    }
+    if (tid == 0) fail_flag[trk] = 0;
+}
+
 // n_steps plant steps of length dt (each RK4 x M); model 3 = kin6, 4 = dyn6, -3 = the node's speed switch + no reversing
 __global__ __launch_bounds__(64) void k_sim_cart(int B, int model, int M, double dt, int n_steps, double v_dyn, const double *xs,
                                                  const double *__restrict__ us, double *xn)
@@ -394,4 +502,11 @@ void ihm2_launch_project(ihm2mpc_handle *h, double s_tol, const double *xc, doub
 {
     hipLaunchKernelGGL(k_project, dim3((h->B + 63) / 64), dim3(64), 0, stream, h->B, h->cfg.nknots, s_tol, h->s_ref, h->X_ref, h->Y_ref,
                        h->phi_ref, h->track_id, xc, s_guess, xf);
+}
+
+// closed-spline fit of every track's centre line on the device: coefficients (ntracks, max_pts, 4) in cX, cY (device); work: ntracks x 7 max_pts x (7 max_pts + 2)
+void ihm2_launch_track_fit(ihm2mpc_handle *h, int max_pts, const int32_t *npts, const double *xy, double curv_weight, double *work, double *cX, double *cY,
+                           int32_t *fail_flag)
+{
+    hipLaunchKernelGGL(k_track_fit, dim3(h->cfg.ntracks), dim3(FIT_T), 0, h->stream, max_pts, npts, xy, curv_weight, work, cX, cY, fail_flag);
 }

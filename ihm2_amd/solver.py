@@ -294,6 +294,21 @@ class BatchedOcpSolver:
         _lib.check(self.lib.ihm2mpc_get_tracks(self._h, _ptr(s_ref), _ptr(kappa), None, None, None))
         self._s_ref, self._kappa_ref = s_ref, kappa          # the host copies the per-instance shim compares "p" against
 
+    def fit_tracks(self, center_lines, curv_weight: float = 2.0):
+        """Closed cubic-spline fit of every track's centre line on the device (``fit_spline``, ``python/motion_planning.py:28-124``; the
+        weight 2.0 is ``offline_motion_plan``'s, ``:358``).  ``center_lines``: one ``(npts_t, 2)`` array per track.  Returns two lists of
+        ``(npts_t, 4)`` coefficient arrays -- what :meth:`build_tracks` takes."""
+        if len(center_lines) != self.ntracks:
+            raise ValueError(f"{self.ntracks} tracks expected")
+        npts = np.array([len(c) for c in center_lines], dtype=np.int32)
+        mx = int(npts.max())
+        xy = np.zeros((self.ntracks, mx, 2))
+        for t, c in enumerate(center_lines):
+            xy[t, :npts[t]] = np.asarray(c, dtype=np.float64)
+        cX = np.zeros((self.ntracks, mx, 4)); cY = np.zeros((self.ntracks, mx, 4))
+        _lib.check(self.lib.ihm2mpc_fit_tracks(self._h, mx, npts.ctypes.data_as(_lib.c_int32_p), _ptr(xy), float(curv_weight), _ptr(cX), _ptr(cY)))
+        return [cX[t, :npts[t]].copy() for t in range(self.ntracks)], [cY[t, :npts[t]].copy() for t in range(self.ntracks)]
+
     def get_tracks(self):
         """``(s_ref, kappa_ref, X_ref, Y_ref, phi_ref)``, each ``(ntracks, nknots)``, as they are on the device."""
         out = [np.empty((self.ntracks, self.nknots)) for _ in range(5)]

@@ -122,8 +122,15 @@ int ihm2mpc_set_tracks(ihm2mpc_handle *h, const double *s_ref, const double *kap
  * :345-399 (offline_motion_plan: heading offset -asin(l_R kappa), lap length) and :402-428 (three laps side by side): nknots = 3 x samples
  * per lap.  coeffs_X, coeffs_Y: (ntracks, max_seg, 4), segment j of track t in [c0, c1, c2, c3] of X(t) = c0 + c1 t + c2 t^2 + c3 t^3,
  * t in [0, 1]; nseg (ntracks): segments of each track (the rest of its rows is ignored).  The closed-spline fit that produces the
- * coefficients (python/motion_planning.py:28-124: one small equality-constrained least-squares problem per track) stays on the host. */
+ * coefficients (python/motion_planning.py:28-124: one small equality-constrained least-squares problem per track): ihm2mpc_fit_tracks, or any host fit. */
 int ihm2mpc_build_tracks(ihm2mpc_handle *h, int32_t max_seg, const int32_t *nseg, const double *coeffs_X, const double *coeffs_Y);
+/* The closed cubic-spline fit itself ON THE DEVICE -- replaces fit_spline of python/motion_planning.py:28-124 (there: qpsolvers / proxqp on
+ * min 1/2 p'Pp + q'p s.t. Ap = 0; here: its KKT system, one workgroup per track, sparse Gaussian elimination with partial pivoting).
+ * xy (ntracks, max_pts, 2): centre-line points of every track, the first npts[t] rows used (closed path: the last point is NOT the first
+ * again); curv_weight: weight of the curvature term (offline_motion_plan uses 2.0, :358); out coeffs_X, coeffs_Y (ntracks, max_pts, 4), host:
+ * feed them to ihm2mpc_build_tracks.  3 <= npts[t] <= max_pts <= 182. */
+int ihm2mpc_fit_tracks(ihm2mpc_handle *h, int32_t max_pts, const int32_t *npts, const double *xy, double curv_weight, double *coeffs_X,
+                       double *coeffs_Y);
 /* read the tables back, (ntracks, nknots) each; any pointer may be NULL */
 int ihm2mpc_get_tracks(ihm2mpc_handle *h, double *s_ref, double *kappa_ref, double *X_ref, double *Y_ref, double *phi_ref);
 int ihm2mpc_set_track_id(ihm2mpc_handle *h, const int32_t *track_id);                     /* (B) */

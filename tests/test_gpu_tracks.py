@@ -62,3 +62,45 @@ def test_device_track_tables_match_the_host_planner_on_all_tracks():
     with pytest.raises(Exception, match="max_seg|segments"):
         s.build_tracks([c[0][:1] for c in cs], [c[1][:1] for c in cs])
     s.free(); s2.free()
+
+
+def test_device_spline_fit_matches_the_independent_restatement_and_feeds_the_tables():
+    """SURVEY.md section 8f N1, the remainder: fit_spline (python/motion_planning.py:28-124) on the device -- `ihm2mpc_fit_tracks`, the KKT system
+    of the reference's programme by sparse Gaussian elimination, one workgroup per track -- against the oracle's null-space fit on all seven
+    tracks (1e-7 of the track's extent: two solution methods of a programme with a 1e-10 regulariser), its KKT residuals, and then the whole
+    pipeline on the device: centre line -> coefficients -> tables, against the oracle's pipeline."""
+    from ihm2_amd import track as T
+    from ihm2_amd.solver import BatchedOcpSolver
+    from oracle import track_np as OT
+
+    names = T.TRACK_NAMES
+    geos = [T.load_track_geometry_data(n) for n in names]
+    nk = 3 * T.NUMBER_SPLINE_INTERVALS
+    dummy = np.tile(np.linspace(0.0, 1.0, nk), (len(names), 1))
+    s = BatchedOcpSolver(make_ocp(), 14, dummy, np.zeros_like(dummy), track_id=np.arange(14) % len(names))
+    cX, cY = s.fit_tracks([g.center_line for g in geos], curv_weight=2.0)
+    for t, g in enumerate(geos):
+        oX, oY = OT.fit_spline_nullspace(g.center_line, 2.0)
+        ext = np.ptp(g.center_line, axis=0).max()
+        assert cX[t].shape == oX.shape
+        assert np.max(np.abs(cX[t] - oX)) < 1e-7 * ext and np.max(np.abs(cY[t] - oY)) < 1e-7 * ext, names[t]
+        feas, stat = OT.kkt_residuals(g.center_line, cX[t], cY[t], 2.0)
+        assert feas < 1e-9 * ext and stat < 1e-8 * ext, (names[t], feas, stat)
+    s.build_tracks(cX, cY)
+    s_ref, kappa, X, Y, phi = s.get_tracks()
+    for t, g in enumerate(geos):
+        mp = OT.motion_plan(g.center_line, g.track_widths)
+        L = mp["lap_length"]
+        assert np.max(np.abs(s_ref[t] - mp["s_ref"])) < 1e-7 * L and np.max(np.abs(X[t] - mp["X_ref"])) < 1e-7 * L and np.max(np.abs(Y[t] - mp["Y_ref"])) < 1e-7 * L
+        assert np.max(np.abs(kappa[t] - mp["kappa_ref"])) < 1e-6 * max(1.0, np.max(np.abs(mp["kappa_ref"])))
+    # another weight, a circle (closed form), and misuse
+    th = 2 * np.pi * np.arange(40) / 40
+    circ = np.column_stack((20 * np.cos(th), 20 * np.sin(th)))
+    s1 = BatchedOcpSolver(make_ocp(), 2, dummy[:1], np.zeros_like(dummy[:1]))
+    c1X, c1Y = s1.fit_tracks([circ], curv_weight=0.5)
+    o1X, o1Y = OT.fit_spline_nullspace(circ, 0.5)
+    assert np.max(np.abs(c1X[0] - o1X)) < 1e-8 * 40 and np.max(np.abs(c1Y[0] - o1Y)) < 1e-8 * 40
+    assert np.max(np.abs(np.hypot(c1X[0][:, 0], c1Y[0][:, 0]) - 20.0)) < 0.05          # the smoothed points stay on the circle
+    with pytest.raises(Exception, match="max_pts|points"):
+        s1.fit_tracks([circ[:2]])
+    s.free(); s1.free()
