@@ -1040,7 +1040,7 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
         if (rc == 0) HIP_TRY(hipEventRecord(h->ev[2], h->stream));
     }
     if (rc != 0) {
-        if (freeze) return fail("no persistent loop for this configuration (needs the fkin6 OCP, batch-shared weights and rows for soft tables, and a batch of at most %d): call ihm2mpc_step per control period", 4 * h->n_cu);
+        if (freeze) return fail("no persistent loop for this configuration (needs batch-shared weights and rows for soft tables or the collocation integrator, and a batch of at most %d): call ihm2mpc_step per control period", 4 * h->n_cu);
         for (size_t i = 0; i < n; i++) {      // launches per step, histories by device-to-device copies in stream order
             if (ihm2mpc_step(h, model, M_sim, s_target)) return -1;
             HIP_TRY(hipMemcpyAsync(h->hist_u0 + i * B * 2, h->u0, B * 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));

@@ -933,14 +933,23 @@ __device__ __noinline__ void call_integrate_fkin6(const double *xk, const double
 {
     dev_integrate_sens<IHM2MPC_MODEL_FKIN6>(xk, uk, x_next, tid, M, dt, nknots, s_ref, kappa_ref, rec, xn_out, nullptr);
 }
+// The dynamic OCP models (python/models.py:455-606; fdyn6u = the named deviation): dev_integrate_sens with the sub-step's base sensitivities
+// parked in LDS (Sl: the QP's LDS, idle during the linearisation; 55 words per lane) -- the arithmetic of k_linearize_dyn.
+template <int MODEL>
+__device__ __noinline__ void call_integrate_dyn(const double *xk, const double *uk, const double *x_next, int tid, int M, double dt, int nknots,
+                                                const double *s_ref, const double *kappa_ref, double *rec, double *Sl)
+{
+    dev_integrate_sens<MODEL>(xk, uk, x_next, tid, M, dt, nknots, s_ref, kappa_ref, rec, nullptr, Sl);
+}
 // the collocation integrator in the loop: the wave's 16 quads take the intervals base .. base + 15 (kernels_irk.hip: four lanes per interval)
-__device__ __noinline__ void call_linearize_irk_fkin6(const IrkTab *tab, int b, int base, int N, int nknots, const double *s_ref, const double *kappa_ref, int tid,
-                                                      const double *x, const double *u, double *lin)
+template <int MODEL>
+__device__ __noinline__ void call_linearize_irk(const IrkTab *tab, int b, int base, int N, int nknots, const double *s_ref, const double *kappa_ref, int tid,
+                                                const double *x, const double *u, double *lin)
 {
     const int st = threadIdx.x & 3, q = base + ((int)threadIdx.x >> 2), k = min(q, N - 1);
     const IrkRows rows = irk_rows_from(tab, st);
-    irk_linearize_quad<IHM2MPC_MODEL_FKIN6>(st, rows, x + ((size_t)b * (N + 1) + k) * 8, u + ((size_t)b * N + k) * 2, tid, nknots, s_ref, kappa_ref,
-                                            lin + ((size_t)b * N + k) * LIN_REC, q < N);
+    irk_linearize_quad<MODEL>(st, rows, x + ((size_t)b * (N + 1) + k) * 8, u + ((size_t)b * N + k) * 2, tid, nknots, s_ref, kappa_ref,
+                              lin + ((size_t)b * N + k) * LIN_REC, q < N);
 }
 __device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
                                            const int32_t *track_id, const double *xs, const double *us, double *xn)
@@ -969,18 +978,15 @@ __device__ __noinline__ void call_sim_irk(const IrkTab *tab, int b, int model, i
         for (int a = 0; a < 8; a++) x0[(size_t)b * 8 + a] = x[a];
 }
 
-__device__ __noinline__ void call_line_search_fkin6(const LsArgs &ls, int b, int it, int last)
+template <int MODEL, bool ROLL>
+__device__ __noinline__ void call_line_search(const LsArgs &ls, int b, int it, int last)
 {
-    line_search_body<IHM2MPC_MODEL_FKIN6>(ls, b, it, last);
-}
-
-__device__ __noinline__ void call_line_search_fkin6_irk(const LsArgs &ls, int b, int it, int last)
-{
-    line_search_body<IHM2MPC_MODEL_FKIN6, true>(ls, b, it, last);
+    line_search_body<MODEL, ROLL>(ls, b, it, last);
 }
 
 struct StepArgs {
     int n_steps, model, M_sim, M, nknots, lap_wrap, freeze;
+    int ocp_model;                          // the model of the shooting intervals (IHM2MPC_MODEL_FKIN6 / FDYN6 / FDYN6U); `model` is the plant's
     int sqp_iters;                          // 0: one RTI iteration per step; > 0: SQP mode, that many iterations with the line search
     double s_target, dt, lap_stop;
     const double *s_ref, *kappa_ref;
@@ -1059,16 +1065,27 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             {
                 const int tid = a.track_id[b];
                 const bool with_plant = kin_plant && it == 0 && act;
+                const int om = s.ocp_model;         // wave-uniform
                 if (IRK) {
-                    for (int base = 0; base < N; base += 16)
-                        call_linearize_irk_fkin6(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                    for (int base = 0; base < N; base += 16) {
+                        if (om == IHM2MPC_MODEL_FKIN6) call_linearize_irk<IHM2MPC_MODEL_FKIN6>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                        else if (om == IHM2MPC_MODEL_FDYN6U) call_linearize_irk<IHM2MPC_MODEL_FDYN6U>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                        else call_linearize_irk<IHM2MPC_MODEL_FDYN6>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                    }
                 } else
                 for (int k = lane; k < N + (with_plant ? 1 : 0); k += 64) {
                     const bool plant = k == N;
                     const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
                     const double *uk = plant ? a.u0 + (size_t)b * 2 : a.u + ((size_t)b * N + k) * 2;
-                    call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, tid, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref,
-                                         plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC, plant ? s.x0 + (size_t)b * 8 : nullptr);
+                    double *rec = plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC;
+                    // (the kinematic plant of a dynamic OCP is the fkin6 integrator on its own lane, after the interval lanes)
+                    if (plant || om == IHM2MPC_MODEL_FKIN6)
+                        call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, tid, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec,
+                                             plant ? s.x0 + (size_t)b * 8 : nullptr);
+                    else if (om == IHM2MPC_MODEL_FDYN6U)
+                        call_integrate_dyn<IHM2MPC_MODEL_FDYN6U>(xk, uk, xk + 8, tid, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec, sm + lane);
+                    else
+                        call_integrate_dyn<IHM2MPC_MODEL_FDYN6>(xk, uk, xk + 8, tid, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec, sm + lane);
                 }
             }
             __syncthreads();
@@ -1088,8 +1105,10 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm, SQP || step + 1 == s.n_steps);
             __syncthreads();
             if (SQP) {
-                if (IRK) call_line_search_fkin6_irk(ls, b, it, it == n_it - 1);
-                else call_line_search_fkin6(ls, b, it, it == n_it - 1);
+                const int om = s.ocp_model, last = it == n_it - 1;
+                if (om == IHM2MPC_MODEL_FKIN6) call_line_search<IHM2MPC_MODEL_FKIN6, IRK != 0>(ls, b, it, last);
+                else if (om == IHM2MPC_MODEL_FDYN6U) call_line_search<IHM2MPC_MODEL_FDYN6U, IRK != 0>(ls, b, it, last);
+                else call_line_search<IHM2MPC_MODEL_FDYN6, IRK != 0>(ls, b, it, last);
                 __syncthreads();
             }
         }
@@ -1148,7 +1167,6 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
                            double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
 #endif
 {
-    if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return 1;
     const bool irk_plant = h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK;     // the plants by collocation (python/main.py:395-400: Radau IIA x M_sim)
     if (irk_plant && ihm2_upload_sim_irk_tab(h, M_sim)) return 1;
     const bool irk = h->cfg.integrator_type != IHM2MPC_INTEG_ERK;       // collocation step on the shooting intervals: batch-shared tables only
@@ -1163,8 +1181,11 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
 #endif
     const size_t lds = qp_lds_bytes(h);
     if (lds > 160 * 1024) return 1;
+    // the dynamic models' RK4 integrator parks its base sensitivities in the QP's LDS
+    if (h->cfg.model != IHM2MPC_MODEL_FKIN6 && !irk && lds < (size_t)s_count(1) * 64 * sizeof(double)) return 1;
     QpArgs a = qp_args(h);
     StepArgs s;
+    s.ocp_model = h->cfg.model;
     s.n_steps = n_steps; s.model = model; s.M_sim = M_sim; s.M = h->cfg.M; s.nknots = h->cfg.nknots; s.lap_wrap = h->lap_wrap ? 1 : 0;
     s.freeze = freeze; s.s_target = s_target; s.dt = h->cfg.dt; s.lap_stop = lap_stop;
     s.sqp_iters = sqp ? (h->cfg.nlp_solver_max_iter > 0 ? h->cfg.nlp_solver_max_iter : 1) : 0;

@@ -76,7 +76,8 @@ extern "C" {
  * sensitivities by the implicit-function theorem; GL4 = GAUSS_LEGENDRE (acados' default, python/main.py:234-236), RADAU4 =
  * GAUSS_RADAU_IIA (python/main.py:395-400, python/sim.py:28-33).  Both NLP solver types run on either integrator (the live options of
  * python/main.py:227-238 are SQP + MERIT_BACKTRACKING + IRK); the persistent loop (ihm2mpc_run_steps in one launch) takes RK4 or IRK on the
- * shooting intervals (all-hard, batch-shared tables for IRK) with an RK4 plant, and falls back to launches per step otherwise. */
+ * shooting intervals (batch-shared tables for IRK) of the kinematic and the dynamic OCP models, with RK4 or Radau IIA plants, and falls back to
+ * launches per step otherwise. */
 #define IHM2MPC_INTEG_ERK 0
 #define IHM2MPC_INTEG_IRK_GL4 1
 #define IHM2MPC_INTEG_IRK_RADAU4 2
@@ -263,8 +264,8 @@ int ihm2mpc_reserve_history(ihm2mpc_handle *h, int32_t n_steps);
  * for batches of more than one instance per compute unit; smaller batches take the latency kernels in ihm2mpc_step (four wavefronts
  * per instance in the QP -- the environment variable IHM2MPC_BLOCK_QP=0 turns that off --, results equal to 1e-9); ihm2mpc_step, ihm2mpc_solve and
  * ihm2mpc_compute_control linearise batches of up to 128 intervals (batch <= 3 at N = 40) one sensitivity column per wavefront
- * (the latency path of the single real-time controller), whose records agree with the loop's to 1e-15, not bit for bit.  The persistent loop exists for the fkin6 OCP -- all-hard constraint tables (the
- * reference's OCP) and soft / track-row tables with batch-shared weights and rows, in the RTI and the SQP mode --
+ * (the latency path of the single real-time controller), whose records agree with the loop's to 1e-15, not bit for bit.  The persistent loop exists for the three OCP models (fkin6, fdyn6,
+ * fdyn6u) -- all-hard constraint tables (the reference's OCP) and soft / track-row tables with batch-shared weights and rows, in the RTI and the SQP mode --
  * and pays off while every instance has a wavefront of its own (batch <= 4 per compute unit); any other case runs
  * n_steps x ihm2mpc_step internally (freeze == 0) or is refused (freeze != 0).
  * freeze != 0: the rules of the reference's loop per car -- a solve status other than 0 / 2 (python/main.py:326-328) or a NaN
