@@ -1003,7 +1003,9 @@ struct StepArgs {
 // IRK = 1: the shooting intervals are integrated by the collocation step of kernels_irk.hip (three passes of 16 quads); the kinematic plant
 // stays RK4 x M_sim and takes a phase of its own on lane 0 like the dynamic plants (the state-only rollout: it no longer rides along
 // with the interval lanes).
-template <int NSLOT, int NSOFT, int PATH, int UNI, int SQP, int IRK = 0>
+// DYN = 1: the shooting intervals carry a dynamic OCP model (StepArgs.ocp_model: fdyn6 or fdyn6u, chosen per launch); a template parameter so
+// that the kinematic kernels stay what they were (the run-time choice alone cost the benchmarked kernel 2 %: 988 k -> 968 k solves/s).
+template <int NSLOT, int NSOFT, int PATH, int UNI, int SQP, int IRK = 0, int DYN = 0>
 __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, const LsArgs *lsp)
 {
     // the loop's own arguments are read from device memory where they are used: as by-value kernel arguments they stayed in
@@ -1065,12 +1067,14 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             {
                 const int tid = a.track_id[b];
                 const bool with_plant = kin_plant && it == 0 && act;
-                const int om = s.ocp_model;         // wave-uniform
+                const int om = DYN ? s.ocp_model : IHM2MPC_MODEL_FKIN6;         // wave-uniform
                 if (IRK) {
                     for (int base = 0; base < N; base += 16) {
-                        if (om == IHM2MPC_MODEL_FKIN6) call_linearize_irk<IHM2MPC_MODEL_FKIN6>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
-                        else if (om == IHM2MPC_MODEL_FDYN6U) call_linearize_irk<IHM2MPC_MODEL_FDYN6U>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
-                        else call_linearize_irk<IHM2MPC_MODEL_FDYN6>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                        if constexpr (!DYN) call_linearize_irk<IHM2MPC_MODEL_FKIN6>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                        else {
+                            if (om == IHM2MPC_MODEL_FDYN6U) call_linearize_irk<IHM2MPC_MODEL_FDYN6U>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                            else call_linearize_irk<IHM2MPC_MODEL_FDYN6>(s.irk_tab, b, base, N, s.nknots, s.s_ref, s.kappa_ref, tid, a.x, a.u, s.lin);
+                        }
                     }
                 } else
                 for (int k = lane; k < N + (with_plant ? 1 : 0); k += 64) {
@@ -1079,13 +1083,15 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
                     const double *uk = plant ? a.u0 + (size_t)b * 2 : a.u + ((size_t)b * N + k) * 2;
                     double *rec = plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC;
                     // (the kinematic plant of a dynamic OCP is the fkin6 integrator on its own lane, after the interval lanes)
-                    if (plant || om == IHM2MPC_MODEL_FKIN6)
+                    if (!DYN || plant)
                         call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, tid, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec,
                                              plant ? s.x0 + (size_t)b * 8 : nullptr);
-                    else if (om == IHM2MPC_MODEL_FDYN6U)
-                        call_integrate_dyn<IHM2MPC_MODEL_FDYN6U>(xk, uk, xk + 8, tid, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec, sm + lane);
-                    else
-                        call_integrate_dyn<IHM2MPC_MODEL_FDYN6>(xk, uk, xk + 8, tid, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec, sm + lane);
+                    else if constexpr (DYN != 0) {
+                        if (om == IHM2MPC_MODEL_FDYN6U)
+                            call_integrate_dyn<IHM2MPC_MODEL_FDYN6U>(xk, uk, xk + 8, tid, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec, sm + lane);
+                        else
+                            call_integrate_dyn<IHM2MPC_MODEL_FDYN6>(xk, uk, xk + 8, tid, s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec, sm + lane);
+                    }
                 }
             }
             __syncthreads();
@@ -1105,10 +1111,12 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm, SQP || step + 1 == s.n_steps);
             __syncthreads();
             if (SQP) {
-                const int om = s.ocp_model, last = it == n_it - 1;
-                if (om == IHM2MPC_MODEL_FKIN6) call_line_search<IHM2MPC_MODEL_FKIN6, IRK != 0>(ls, b, it, last);
-                else if (om == IHM2MPC_MODEL_FDYN6U) call_line_search<IHM2MPC_MODEL_FDYN6U, IRK != 0>(ls, b, it, last);
-                else call_line_search<IHM2MPC_MODEL_FDYN6, IRK != 0>(ls, b, it, last);
+                const int last = it == n_it - 1;
+                if constexpr (!DYN) call_line_search<IHM2MPC_MODEL_FKIN6, IRK != 0>(ls, b, it, last);
+                else {
+                    if (s.ocp_model == IHM2MPC_MODEL_FDYN6U) call_line_search<IHM2MPC_MODEL_FDYN6U, IRK != 0>(ls, b, it, last);
+                    else call_line_search<IHM2MPC_MODEL_FDYN6, IRK != 0>(ls, b, it, last);
+                }
                 __syncthreads();
             }
         }
@@ -1125,11 +1133,12 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
 
 }  // namespace
 
-// This file is compiled TWICE (Makefile) only to halve the build time: QP_SET = 0 holds the all-hard instantiations (the reference's
-// OCP), QP_SET = 1 the soft / track-row instantiations -- same flags, same (default) scheduler.  `make ilp` builds both again under
+// This file is compiled THREE times (Makefile): QP_SET = 0 holds the all-hard instantiations (the reference's OCP), QP_SET = 1 the
+// soft / track-row instantiations, QP_SET = 2 the persistent loop of the dynamic OCP models (all tables) -- same flags, same (default)
+// scheduler.  Separate objects are separate device code images: the benchmarked kernels' image does not move when another set grows.  `make ilp` builds both again under
 // LLVM's iterative ILP scheduler into the test artefact libihm2mpc_ilp.so (tests/test_gpu_configs.py compares the two builds).
 #ifndef QP_SET
-#error "compile with -DQP_SET=0 (all-hard instantiations) or -DQP_SET=1 (soft / track-row instantiations)"
+#error "compile with -DQP_SET=0 (all-hard instantiations), -DQP_SET=1 (soft / track-row instantiations) or -DQP_SET=2 (dynamic OCP models in the persistent loop)"
 #endif
 static size_t qp_lds_bytes(const ihm2mpc_handle *h)
 {
@@ -1160,13 +1169,26 @@ static QpArgs qp_args(ihm2mpc_handle *h)
 #if QP_SET == 0
 int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
                            double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it);
+int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
+                          double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it);
 int ihm2_launch_steps(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
                       double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
-#else
+#elif QP_SET == 1
 int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
                            double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
+#else
+int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_target, int n_steps, int freeze, double lap_stop,
+                          double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
 #endif
 {
+    const bool dyn = h->cfg.model != IHM2MPC_MODEL_FKIN6;
+#if QP_SET == 0
+    if (dyn) return ihm2_launch_steps_dyn(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
+#elif QP_SET == 1
+    if (dyn) return 1;
+#else
+    if (!dyn || !(h->uniform_H && h->uniform_CD)) return 1;     // the dynamic models come with batch-shared tables only (the reference's OCP has them)
+#endif
     const bool irk_plant = h->cfg.sim_integrator_type != IHM2MPC_INTEG_ERK;     // the plants by collocation (python/main.py:395-400: Radau IIA x M_sim)
     if (irk_plant && ihm2_upload_sim_irk_tab(h, M_sim)) return 1;
     const bool irk = h->cfg.integrator_type != IHM2MPC_INTEG_ERK;       // collocation step on the shooting intervals: batch-shared tables only
@@ -1176,7 +1198,7 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8;
 #if QP_SET == 0
     if (!hard) return ihm2_launch_steps_soft(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
-#else
+#elif QP_SET == 1
     if (hard) return 1;
 #endif
     const size_t lds = qp_lds_bytes(h);
@@ -1215,59 +1237,55 @@ int ihm2_launch_steps_soft(ihm2mpc_handle *h, int model, int M_sim, double s_tar
     const StepArgs *sdev = (const StepArgs *)h->step_args;
     const LsArgs *ls = (const LsArgs *)h->ls_args;
     const int uni = h->uniform_H && h->uniform_CD;
-#define LAUNCH_STEPS_1(NS_, NO_, PT_, UN_, SQ_)                                                                                         \
-    do {                                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)k_steps<NS_, NO_, PT_, UN_, SQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_steps<NS_, NO_, PT_, UN_, SQ_>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                      \
+    // one instantiation: slots per lane, soft slots per lane, track rows, batch-shared tables, SQP mode, collocation, dynamic model
+#define LAUNCH_K(NS_, NO_, PT_, UN_, SQ_, IR_, DY_)                                                                                        \
+    do {                                                                                                                                    \
+        (void)hipFuncSetAttribute((const void *)k_steps<NS_, NO_, PT_, UN_, SQ_, IR_, DY_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_steps<NS_, NO_, PT_, UN_, SQ_, IR_, DY_>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                \
     } while (0)
-#if QP_SET == 0
-#define LAUNCH_STEPS_IRK(NS_, SQ_)                                                                                                     \
-    do {                                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)k_steps<NS_, 0, 0, 1, SQ_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-        hipLaunchKernelGGL((k_steps<NS_, 0, 0, 1, SQ_, 1>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                         \
+    // SQP mode and integrator at run time
+#if QP_SET == 2
+#define LAUNCH_STEPS(NS_, NO_, PT_, UN_)                                                                                                   \
+    do {                                                                                                                                    \
+        if (irk) { if (sqp) LAUNCH_K(NS_, NO_, PT_, 1, 1, 1, 1); else LAUNCH_K(NS_, NO_, PT_, 1, 0, 1, 1); }                                \
+        else { if (sqp) LAUNCH_K(NS_, NO_, PT_, 1, 1, 0, 1); else LAUNCH_K(NS_, NO_, PT_, 1, 0, 0, 1); }                                    \
     } while (0)
-    if (irk) {
-        if (h->nslot_lane <= 5) { if (sqp) LAUNCH_STEPS_IRK(5, 1); else LAUNCH_STEPS_IRK(5, 0); }
-        else { if (sqp) LAUNCH_STEPS_IRK(8, 1); else LAUNCH_STEPS_IRK(8, 0); }
-        return 0;
-    }
-#undef LAUNCH_STEPS_IRK
-#define LAUNCH_STEPS(NS_, UN_) do { if (sqp) LAUNCH_STEPS_1(NS_, 0, 0, UN_, 1); else LAUNCH_STEPS_1(NS_, 0, 0, UN_, 0); } while (0)
-    if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 1); else LAUNCH_STEPS(5, 0); }
-    else { if (uni) LAUNCH_STEPS(8, 1); else LAUNCH_STEPS(8, 0); }
-#undef LAUNCH_STEPS
 #else
-    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them)
-    if (!uni) return 1;
-    const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
-#define LAUNCH_STEPS_IRK1(NS_, NO_, PT_, SQ_)                                                                                          \
-    do {                                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)k_steps<NS_, NO_, PT_, 1, SQ_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_steps<NS_, NO_, PT_, 1, SQ_, 1>), dim3(h->B), dim3(64), lds, h->stream, sdev, a, ls);                     \
+#define LAUNCH_STEPS(NS_, NO_, PT_, UN_)                                                                                                   \
+    do {                                                                                                                                    \
+        if (irk) { if (sqp) LAUNCH_K(NS_, NO_, PT_, 1, 1, 1, 0); else LAUNCH_K(NS_, NO_, PT_, 1, 0, 1, 0); }                                \
+        else { if (sqp) LAUNCH_K(NS_, NO_, PT_, UN_, 1, 0, 0); else LAUNCH_K(NS_, NO_, PT_, UN_, 0, 0, 0); }                                \
     } while (0)
-#define LAUNCH_STEPS(NS_, NO_, PT_)                                                                                                     \
-    do {                                                                                                                                \
-        if (irk) { if (sqp) LAUNCH_STEPS_IRK1(NS_, NO_, PT_, 1); else LAUNCH_STEPS_IRK1(NS_, NO_, PT_, 0); }                            \
-        else if (sqp) LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 1);                                                                              \
-        else LAUNCH_STEPS_1(NS_, NO_, PT_, 1, 0);                                                                                       \
-    } while (0)
-    if (!h->path_on) {
-        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 0);
-        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0);
-        else return 1;
-    } else {
-        if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 1);
-        else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS(8, 3, 1);
-        else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 1);
-        else return 1;
-    }
-#undef LAUNCH_STEPS
-#undef LAUNCH_STEPS_IRK1
 #endif
-#undef LAUNCH_STEPS_1
+#if QP_SET != 1
+    if (hard) {
+        if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 0, 0, 1); else LAUNCH_STEPS(5, 0, 0, 0); }
+        else { if (uni) LAUNCH_STEPS(8, 0, 0, 1); else LAUNCH_STEPS(8, 0, 0, 0); }
+    }
+#endif
+#if QP_SET != 0
+    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them)
+    if (!hard) {
+        if (!uni) return 1;
+        const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
+        if (!h->path_on) {
+            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 0, 1);
+            else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0, 1);
+            else return 1;
+        } else {
+            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 1, 1);
+            else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS(8, 3, 1, 1);
+            else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 1, 1);
+            else return 1;
+        }
+    }
+#endif
+#undef LAUNCH_STEPS
+#undef LAUNCH_K
     return 0;
 }
 
+#if QP_SET != 2
 #if QP_SET == 0
 int ihm2_launch_qp_hard(ihm2mpc_handle *h)
 #else
@@ -1324,3 +1342,4 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
 #undef LAUNCH_QP
     return 0;
 }
+#endif
