@@ -7,7 +7,7 @@ SRC = os.path.join(ROOT, "ihm2_amd", "csrc")
 BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 QP = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 jobs = [(f, []) for f in ("kernels_misc.hip", "kernels_linearize.hip", "kernels_cart.hip", "kernels_dyn10.hip", "kernels_sqp.hip", "kernels_irk.hip")]
-jobs += [("kernels_qp.hip", ["-DQP_SET=0"] + QP), ("kernels_qp.hip", ["-DQP_SET=1"] + QP)]
+jobs += [("kernels_qp.hip", ["-DQP_SET=0"] + QP), ("kernels_qp.hip", ["-DQP_SET=1"] + QP), ("kernels_qp.hip", ["-DQP_SET=2"] + QP)]
 for f, extra in jobs:
     out = subprocess.run(BASE + extra + [f], cwd=SRC, capture_output=True, text=True).stderr
     cur = None
