@@ -425,13 +425,25 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     int qstatus = 1, it = 0;
     bool exact_mode = false;     // residuals from the problem data in every iteration (set when followed residuals failed their check)
     double res_g = 0, res_b = 0, res_d = 0, res_m = 0, mu = 0;
+    double fol_g = 0.0, fol_b = 0.0;        // this lane's share of max |r_g|, max |r_b| of the followed residuals (formed where the update writes them)
     double rd_l[NSLOT], rd_u[NSLOT], dlam_l[NSLOT], dlam_u[NSLOT], dt_l[NSLOT], dt_u[NSLOT];
     double pa_l[NSLOT], pa_u[NSLOT];      // dlam * dt of the predictor (only the products enter the corrector): 2 registers per slot less than the factors
     for (it = 0;; it++) {
 /*@S:1*/
-        // ---- slack residuals, complementarity; lam_l - lam_u -> cf ----
-        for (int e = tid; e < NS * NCK; e += NT) cf[e] = 0.0;
-        BSYNC();
+        // ---- slack residuals, complementarity; lam_l - lam_u -> cf (read by the exact stationarity residual only) ----
+        bool exact = (it == 0) || exact_mode, finished = false;
+        auto multipliers_to_cf = [&]() {
+            for (int e = tid; e < NS * NCK; e += NT) cf[e] = 0.0;
+            BSYNC();
+#pragma unroll
+            for (int r = 0; r < NSLOT; r++) {
+                if (s_kc[r] < 0) continue;
+                const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+                SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));     // the two halves of a split slot share a lane
+            }
+            BSYNC();
+        };
+        if (exact) multipliers_to_cf();
         double mu_acc = 0.0, res_gs = 0.0;
         res_d = 0.0; res_m = 0.0;
 #pragma unroll
@@ -450,17 +462,14 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 res_gs = nanmax(res_gs, fabs(so_rs[q]));
                 mu_acc += so_ls[q] * so_s[q]; res_m = nanmax(res_m, fabs(so_ls[q] * so_s[q]));
             }
-            SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));     // the two halves of a split slot share a lane
         }
 /*@S:14*/
-        BSYNC();
         // ---- stationarity and dynamics residuals ----
         // exact: formed from the problem data -- (i) the terms without [A B], g + H z - pi_k - R'(lam_l - lam_u), then (ii) [A B]'pi_{k+1}
         // and r_b from the records.  Otherwise they are what the update at the end of the previous iteration left in rgb / rb: the
         // Newton step solves the linearised rows exactly, so the residuals follow the step (no pass over the records).  Followed residuals
         // that pass the convergence test are formed from the data and tested again; should that fail, every later iteration forms them
         // from the data (exact_mode).
-        bool exact = (it == 0) || exact_mode, finished = false;
         for (int rpass = 0; rpass < 2; rpass++) {
             if (exact) {
                 // (an unrolled variant that forms all values before the first store -- QP gradient entries and LDS operands of all passes in
@@ -497,14 +506,16 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             }       // (otherwise gt already holds the followed residual: the update at the end of the previous iteration left it there)
 /*@S:3*/
             res_g = 0.0; res_b = 0.0;
-            for (int e = tid; e < NS * 10; e += NT) {
-                const int k = e / 10, j = e % 10;
-                double v = gt[e];
-                if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
-                if (exact) rgb[e] = v;          // the residual the update at the end of the iteration carries on
-                res_g = nanmax(res_g, fabs(v));
-            }
-            for (int e = tid; e < N * 8; e += NT) res_b = nanmax(res_b, fabs(rb[e]));
+            if (exact) {
+                for (int e = tid; e < NS * 10; e += NT) {
+                    const int k = e / 10, j = e % 10;
+                    double v = gt[e];
+                    if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
+                    rgb[e] = v;          // the residual the update at the end of the iteration carries on
+                    res_g = nanmax(res_g, fabs(v));
+                }
+                for (int e = tid; e < N * 8; e += NT) res_b = nanmax(res_b, fabs(rb[e]));
+            } else { res_g = fol_g; res_b = fol_b; }        // the update that wrote the followed residuals took their norms (masked entries are stored as zeros)
             res_g = nanmax(res_g, res_gs);
             res_g = blk_nanmax(res_g); res_b = blk_nanmax(res_b);
             if (rpass == 0) { res_d = blk_nanmax(res_d); res_m = blk_nanmax(res_m); mu = blk_sum(mu_acc) * inv_m; }
@@ -512,6 +523,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) {
                 if (exact) { qstatus = 0; finished = true; break; }
                 exact = true; exact_mode = true;        // the followed residuals say converged: check against the data
+                multipliers_to_cf();
                 continue;
             }
             break;
@@ -813,6 +825,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             // the slot registers -- 904 k against 965 k solves/s over 20 steps.)
             const double cd = 1.0 - alpha_d, cp = alpha - alpha_d, cb = 1.0 - alpha;
             const int n10 = NS * 10;
+            fol_g = 0.0; fol_b = 0.0;
             for (int base = 0; base < n10; base += 4 * NT) {
                 double ro[4];
 #pragma unroll
@@ -831,12 +844,13 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     }
                     const bool masked = (k == 0 && j < 8) || (k == N && j >= 8);
                     const double v = masked ? 0.0 : fma(cp, hdz, cd * ro[q]);
-                    if (e < n10) { rgb[e] = v; gt[e] = v; }
+                    if (e < n10) { rgb[e] = v; gt[e] = v; fol_g = nanmax(fol_g, fabs(v)); }
                 }
             }
             for (int e = tid; e < N * 8; e += NT) {
                 const double v = cb * rb[e];
                 rb[e] = v;
+                fol_b = nanmax(fol_b, fabs(v));
                 const_cast<double *>(linb)[(size_t)(e >> 3) * LIN_REC + RIC_REC_RB + (e & 7)] = v;
             }
         }
