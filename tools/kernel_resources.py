@@ -10,17 +10,17 @@ jobs = [(f, []) for f in ("kernels_misc.hip", "kernels_linearize.hip", "kernels_
 jobs += [("kernels_qp.hip", ["-DQP_SET=0"] + QP), ("kernels_qp.hip", ["-DQP_SET=1"] + QP), ("kernels_qp.hip", ["-DQP_SET=2"] + QP)]
 for f, extra in jobs:
     out = subprocess.run(BASE + extra + [f], cwd=SRC, capture_output=True, text=True).stderr
-    cur = None
+    recs, cur = [], None
     for line in out.splitlines():
-        m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
+        m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\S+)", line)
         if not m: continue
         k, v = m.group(1), m.group(2)
         if k == "Function Name":
-            cur = {"name": subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()}
+            cur = {"mangled": v}; recs.append(cur)
         elif cur is not None:
-            cur[k.split(" ")[0]] = v
-            if k.startswith("LDS"):
-                n = cur["name"].replace("(anonymous namespace)::", "").replace("void ", "")
-                n = re.sub(r"\(.*", "", n)
-                print(f"{f:22s} {n:40s} VGPRs {cur.get('VGPRs'):>3s}  AGPRs {cur.get('AGPRs'):>3s}  scratch {cur.get('ScratchSize'):>5s} B/lane  occupancy {cur.get('Occupancy')} waves/SIMD")
-                cur = None
+            cur.setdefault(k.split(" ")[0], v)
+    names = subprocess.run(["c++filt"], input="\n".join(r["mangled"] for r in recs), capture_output=True, text=True).stdout.splitlines()
+    for r, n in zip(recs, names):
+        if "k_" not in n: continue          # kernels only (device functions called from them are listed by the compiler as well)
+        n = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("void ", ""))
+        print(f"{f:22s} {n:40s} VGPRs {r.get('VGPRs', '?'):>3s}  AGPRs {r.get('AGPRs', '?'):>3s}  scratch {r.get('ScratchSize', '?'):>5s} B/lane  occupancy {r.get('Occupancy', '?')} waves/SIMD")
