@@ -22,7 +22,7 @@
 #define NC 14   // two-sided constraint rows per stage: 8 state boxes, 2 input boxes, 2 general rows, 2 track rows
 #define NLAM 28
 #define MAX_SLOTS 640   // 10 per lane
-#define QM_PAD 16    // >= 2 x ring depth of the vector / forward sweeps: their unclamped prefetch overshoots an instance by < 2 D rows
+#define QM_PAD 24    // >= 3 x ring depth of the vector / forward sweeps: their unclamped prefetch overshoots an instance by < 3 D rows
 #define LIN_REC 96   // doubles per (instance, interval) linearisation record: A (64) | B (16) | b (8) | rb (8: the QP's dynamics residual, riccati_mfma.hpp)
 
 struct ihm2mpc_comm;      // comm.hip: RCCL communicator + staging buffers of a one-process-per-GPU job

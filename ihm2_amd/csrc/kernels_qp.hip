@@ -141,27 +141,37 @@ __device__ __forceinline__ double sum_stride8(double v)
 template <int DIR, int D, int DL, typename P, typename F>
 __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_even, int e_odd, P &&pre, F &&body)
 {
-    static_assert(D % 2 == 0 && DL % 2 == 0 && D % DL == 0 && 2 * D <= QM_PAD, "the element index alternates with the step parity");
-    // The prefetches run UNCLAMPED past the instance, by at most ceil(N/D) D + D - N < 2 D rows (D + DL stages of LDS
-    // operands): the streamed array is padded by QM_PAD >= 2 D rows at both ends and the LDS operands sit inside the kernel's LDS carve-up with other arrays on both sides,
+    static_assert(D % 2 == 0 && DL % 2 == 0 && D % DL == 0 && 3 * D <= QM_PAD, "the element index alternates with the step parity");
+    // The prefetches run UNCLAMPED past the instance, by at most ceil(N / 2D) 2D + D - N < 3 D rows (D + DL stages of LDS
+    // operands): the streamed array is padded by QM_PAD >= 3 D rows at both ends and the LDS operands sit inside the kernel's LDS carve-up with other arrays on both sides,
     // so every address is valid and the values fetched for stages outside [0, N) are never used.  (Clamping the indices
     // cost a third of the sweep's instructions in scalar min / shift / add chains.)
-    double r[D], x0[DL], x1[DL];
+    // Two register sets used in turn (a stage of the first half of the loop body takes its row from set 0 and refills set 1, the second
+    // half the other way round): every load writes a register whose last value is dead, so nothing has to be copied at the loop's back
+    // edge.  (With ONE set the value in use and its refill were live together, the compiler rotated them with moves at the back edge, and
+    // each move waited for its load: an s_waitcnt vmcnt(0) -- the whole ring drained -- every D stages.)
+    double r[2][D], x0[DL], x1[DL];
     const double *p_even = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_even, *p_odd = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_odd;
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        r[d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * d * 64];
+        r[0][d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * d * 64];
+        // the initial loads are issued in ring order (fence): the wait counts of the loop are the minimum over both ways into it, and a
+        // reordered prologue (oldest slot loaded last) made the steady state wait for all but one load at the top of every pass
+        __builtin_amdgcn_sched_barrier(0);
         if (d < DL) pre((DIR < 0) ? N - 1 - d : d, (d & 1) != 0, x0[d], x1[d]);
     }
-    for (int s0 = 0; s0 < N; s0 += D) {
+    for (int s0 = 0; s0 < N; s0 += 2 * D) {
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            const int s = s0 + d;
-            const int k = (DIR < 0) ? N - 1 - s : s;
-            const double v = r[d], y0 = x0[d % DL], y1 = x1[d % DL];
-            r[d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * (s + D) * 64];
-            pre((DIR < 0) ? k - DL : k + DL, (d & 1) != 0, x0[d % DL], x1[d % DL]);
-            if (s < N) body(k, v, (d & 1) != 0, y0, y1);
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int s = s0 + h * D + d;
+                const int k = (DIR < 0) ? N - 1 - s : s;
+                const double v = r[h][d], y0 = x0[d % DL], y1 = x1[d % DL];
+                r[h ^ 1][d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * (s + D) * 64];
+                pre((DIR < 0) ? k - DL : k + DL, (d & 1) != 0, x0[d % DL], x1[d % DL]);
+                if (s < N) body(k, v, (d & 1) != 0, y0, y1);
+            }
         }
     }
 }
