@@ -151,10 +151,19 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
     // edge.  (With ONE set the value in use and its refill were live together, the compiler rotated them with moves at the back edge, and
     // each move waited for its load: an s_waitcnt vmcnt(0) -- the whole ring drained -- every D stages.)
     double r[2][D], x0[DL], x1[DL];
-    const double *p_even = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_even, *p_odd = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_odd;
+    // Buffer loads: resource descriptor over the instance's rows and their padding (scalar), the row as scalar offset, the lane's element as
+    // 32-bit vector offset -- no 64-bit address arithmetic per lane and load (three vector instructions per stage as global loads).
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rows) - (size_t)QM_PAD * 64, 0, (N + 2 * QM_PAD) * 512, 0x00020000);
+    const unsigned ve = (unsigned)e_even * 8u, vo = (unsigned)e_odd * 8u;
+    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+    auto load_row = [&](const int step, const unsigned voff) -> double {       // step: wave-uniform
+        const int row = (DIR < 0) ? N - 1 - step : step;
+        const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, (QM_PAD + row) * 512, 0);
+        return __hiloint2double((int)v.y, (int)v.x);
+    };
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        r[0][d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * d * 64];
+        r[0][d] = load_row(d, (d & 1) ? vo : ve);
         // the initial loads are issued in ring order (fence): the wait counts of the loop are the minimum over both ways into it, and a
         // reordered prologue (oldest slot loaded last) made the steady state wait for all but one load at the top of every pass
         __builtin_amdgcn_sched_barrier(0);
@@ -168,7 +177,7 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
                 const int s = s0 + h * D + d;
                 const int k = (DIR < 0) ? N - 1 - s : s;
                 const double v = r[h][d], y0 = x0[d % DL], y1 = x1[d % DL];
-                r[h ^ 1][d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * (s + D) * 64];
+                r[h ^ 1][d] = load_row(s + D, (d & 1) ? vo : ve);
                 pre((DIR < 0) ? k - DL : k + DL, (d & 1) != 0, x0[d % DL], x1[d % DL]);
                 if (s < N) body(k, v, (d & 1) != 0, y0, y1);
             }
@@ -639,19 +648,27 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (wv == 0) {
                 const int g = lane >> 3, w = lane & 7;
                 double pw = pv[N * 8 + w], pg = 0.0;
+                // the stage's base term is added by ONE lane of each sum: the other lanes read a word that is zero throughout (dz[0]: dx_0 = 0)
+                // instead of selecting -- and every lane of a sum stores its (identical) result: no select, no exec mask per stage
+                // (running pointers with a per-lane decrement -- 16 doubles or none per two stages: the fetches come in the order k = N-1, N-2, ...
+                // with even and odd steps alternating)
+                const int se2 = (w == 0) ? 16 : 0, so2 = (g == 0) ? 16 : 0;
+                const double *be = (w == 0) ? pv + (N - 1) * 8 + g : dz, *bo = (g == 0) ? pv + (N - 2) * 8 + w : dz;
+                const double *qe = Prb + (N - 1) * 8 + w, *qo = Prb + (N - 2) * 8 + g;      // P_{k+1} rb_k, same order
+                double *oe = pv + (N - 1) * 8 + g, *oo = pv + (N - 2) * 8 + w;               // results: k = N-1, N-3, ... and N-2, N-4, ...
                 stream_rows<-1, 8, 4>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
-                    [&](int k, bool odd, double &prb, double &base) { prb = Prb[k * 8 + (odd ? g : w)]; base = pv[k * 8 + (odd ? w : g)]; },
+                    [&](int k, bool odd, double &prb, double &base) {
+                        if (odd) { prb = *qo; qo -= 16; base = *bo; bo -= so2; } else { prb = *qe; qe -= 16; base = *be; be -= se2; }
+                    },
                     [&](int k, double m, bool odd, double prb, double base) {
-                        // only the product with the carried value sits on the dependent chain: m * prb and the stage's base term (added
-                        // by ONE lane of each sum) are formed as soon as the operands arrive
+                        // only the product with the carried value sits on the dependent chain: m * prb and the stage's base term are
+                        // formed as soon as the operands arrive
                         if (!odd) {
-                            const double off = fma(m, prb, (w == 0) ? base : 0.0);
-                            pg = sum8(fma(m, pw, off));
-                            if (w == 0) pv[k * 8 + g] = pg;
+                            pg = sum8(fma(m, pw, fma(m, prb, base)));
+                            *oe = pg; oe -= 16;
                         } else {
-                            const double off = fma(m, prb, (g == 0) ? base : 0.0);
-                            pw = sum_stride8(fma(m, pg, off));
-                            if (g == 0) pv[k * 8 + w] = pw;
+                            pw = sum_stride8(fma(m, pg, fma(m, prb, base)));
+                            *oo = pw; oo -= 16;
                         }
                     });
             }
@@ -688,16 +705,23 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (wv == 0) {
                 const int g = lane >> 3, w = lane & 7;
                 double dxw = dz[w], dxg = 0.0;
+                // the affine term rides in ONE lane's product (an fma off the dependent chain's critical add); the other lanes read the zero word
+                // dz[0] (dx_0 = 0), and every lane of a sum stores its (identical) result
+                // (running pointers with a per-lane increment: the fetches come in the order k = 0, 1, ... with even and odd steps alternating)
+                const int se2 = (w == 0) ? 20 : 0, so2 = (g == 0) ? 20 : 0;
+                const double *ce = (w == 0) ? dz + 10 + g : dz, *co = (g == 0) ? dz + 20 + w : dz;
                 stream_rows<+1, 8, 4>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
-                    [&](int k, bool odd, double &c, double &unused) { c = dz[(k + 1) * 10 + (odd ? w : g)]; unused = 0.0; },
+                    [&](int k, bool odd, double &c, double &unused) {
+                        if (odd) { c = *co; co += so2; } else { c = *ce; ce += se2; }
+                        unused = 0.0;
+                    },
                     [&](int k, double m, bool odd, double c, double) {
-                        // the affine term rides in ONE lane's product (an fma off the dependent chain's critical add)
                         if (!odd) {
-                            dxg = sum8(fma(m, dxw, (w == 0) ? c : 0.0));
-                            if (w == 0) dz[(k + 1) * 10 + g] = dxg;
+                            dxg = sum8(fma(m, dxw, c));
+                            dz[(k + 1) * 10 + g] = dxg;
                         } else {
-                            dxw = sum_stride8(fma(m, dxg, (g == 0) ? c : 0.0));
-                            if (g == 0) dz[(k + 1) * 10 + w] = dxw;
+                            dxw = sum_stride8(fma(m, dxg, c));
+                            dz[(k + 1) * 10 + w] = dxw;
                         }
                     });
             }
