@@ -66,6 +66,16 @@ struct QpArgs {
 };
 
 #define INF_BOUND 1e20
+// Depths of the prefetch rings: records of the factor sweep (stages ahead), rows of the vector / forward sweeps (a pass of those sweeps is
+// 2 SWEEP_RING stages of straight-line code).  The kernel's loop is as large as the instruction cache two CUs share (k_qp_wave<5,0,0,1>:
+// 77 KB of code, 64 KB of cache): unrolling is paid for in instruction fetches.
+#ifndef RIC_RING
+#define RIC_RING 4
+#endif
+#ifndef SWEEP_RING
+#define SWEEP_RING 4
+#endif
+#define SWEEP_DL ((SWEEP_RING >= 8) ? 4 : 2)       // stages the LDS operands are fetched ahead
 
 // The block is ONE wavefront: its lanes run in lockstep and the LDS serves one wave's instructions in
 // order, so a hand-off through LDS needs no s_barrier -- only a compiler fence.  (A __syncthreads()
@@ -620,7 +630,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             RicLds L;
             L.gt = NS * 10; L.pv = NS * 28; L.gam = NS * 36 + N * 8; L.dz = L.gam + 2 * NS * NCK; L.kff = L.dz + NS * 10; L.Kl = L.kff + N * 4;
             L.Ginv = L.Kl + N * 16; L.hv = L.Ginv + N * 8; L.tile = L.hv + N * 8; L.hc = L.tile + 136;
-            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, 4>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0, a.symmetrize != 0);
+            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, RIC_RING>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0, a.symmetrize != 0);
             if (lane < 8) dz[lane] = 0.0;
         }
         BSYNC();
@@ -656,7 +666,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 const double *be = (w == 0) ? pv + (N - 1) * 8 + g : dz, *bo = (g == 0) ? pv + (N - 2) * 8 + w : dz;
                 const double *qe = Prb + (N - 1) * 8 + w, *qo = Prb + (N - 2) * 8 + g;      // P_{k+1} rb_k, same order
                 double *oe = pv + (N - 1) * 8 + g, *oo = pv + (N - 2) * 8 + w;               // results: k = N-1, N-3, ... and N-2, N-4, ...
-                stream_rows<-1, 8, 4>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
+                stream_rows<-1, SWEEP_RING, SWEEP_DL>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
                     [&](int k, bool odd, double &prb, double &base) {
                         if (odd) { prb = *qo; qo -= 16; base = *bo; bo -= so2; } else { prb = *qe; qe -= 16; base = *be; be -= se2; }
                     },
@@ -710,7 +720,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 // (running pointers with a per-lane increment: the fetches come in the order k = 0, 1, ... with even and odd steps alternating)
                 const int se2 = (w == 0) ? 20 : 0, so2 = (g == 0) ? 20 : 0;
                 const double *ce = (w == 0) ? dz + 10 + g : dz, *co = (g == 0) ? dz + 20 + w : dz;
-                stream_rows<+1, 8, 4>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
+                stream_rows<+1, SWEEP_RING, SWEEP_DL>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
                     [&](int k, bool odd, double &c, double &unused) {
                         if (odd) { c = *co; co += so2; } else { c = *ce; ce += se2; }
                         unused = 0.0;
