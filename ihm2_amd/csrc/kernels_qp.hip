@@ -195,13 +195,53 @@ __device__ __forceinline__ void stream_rows(const double *rows, int N, int e_eve
     }
 }
 
+// The sweeps' row streaming as it was before the diet below (global loads with per-lane 64-bit addresses): kept for the SQP instantiations of the
+// persistent loop, whose register allocation the leaner form tips into scratch (live options: 449 k control steps/s with this form, 380 k with the other).
+template <int DIR, int D, int DL, typename P, typename F>
+__device__ __forceinline__ void stream_rows_v1(const double *rows, int N, int e_even, int e_odd, P &&pre, F &&body)
+{
+    static_assert(D % 2 == 0 && DL % 2 == 0 && D % DL == 0 && 3 * D <= QM_PAD, "the element index alternates with the step parity");
+    // The prefetches run UNCLAMPED past the instance, by at most ceil(N / 2D) 2D + D - N < 3 D rows (D + DL stages of LDS
+    // operands): the streamed array is padded by QM_PAD >= 3 D rows at both ends and the LDS operands sit inside the kernel's LDS carve-up with other arrays on both sides,
+    // so every address is valid and the values fetched for stages outside [0, N) are never used.  (Clamping the indices
+    // cost a third of the sweep's instructions in scalar min / shift / add chains.)
+    // Two register sets used in turn (a stage of the first half of the loop body takes its row from set 0 and refills set 1, the second
+    // half the other way round): every load writes a register whose last value is dead, so nothing has to be copied at the loop's back
+    // edge.  (With ONE set the value in use and its refill were live together, the compiler rotated them with moves at the back edge, and
+    // each move waited for its load: an s_waitcnt vmcnt(0) -- the whole ring drained -- every D stages.)
+    double r[2][D], x0[DL], x1[DL];
+    const double *p_even = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_even, *p_odd = rows + (size_t)((DIR < 0) ? N - 1 : 0) * 64 + e_odd;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        r[0][d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * d * 64];
+        // the initial loads are issued in ring order (fence): the wait counts of the loop are the minimum over both ways into it, and a
+        // reordered prologue (oldest slot loaded last) made the steady state wait for all but one load at the top of every pass
+        __builtin_amdgcn_sched_barrier(0);
+        if (d < DL) pre((DIR < 0) ? N - 1 - d : d, (d & 1) != 0, x0[d], x1[d]);
+    }
+    for (int s0 = 0; s0 < N; s0 += 2 * D) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int s = s0 + h * D + d;
+                const int k = (DIR < 0) ? N - 1 - s : s;
+                const double v = r[h][d], y0 = x0[d % DL], y1 = x1[d % DL];
+                r[h ^ 1][d] = ((d & 1) ? p_odd : p_even)[(ptrdiff_t)DIR * (s + D) * 64];
+                pre((DIR < 0) ? k - DL : k + DL, (d & 1) != 0, x0[d % DL], x1[d % DL]);
+                if (s < N) body(k, v, (d & 1) != 0, y0, y1);
+            }
+        }
+    }
+}
+
 // The QP of instance b, solved by the calling wavefront (all 64 lanes, lane = threadIdx.x); sm: the block's dynamic LDS.
 // Called by k_qp_wave (one launch per RTI iteration) and by the persistent per-instance loop k_steps.
 // NW > 1 (k_qp_block, the latency kernel for batches smaller than the chip): NW wavefronts share the instance.  The phases that
 // are parallel over stages / rows run over all NT = 64 NW threads, the constraint slots are spread over NT lanes (NSLOT is then the
 // count per lane of THAT table), reductions go wave -> LDS -> block, hand-offs are s_barriers; the three sequential sweeps run on
 // wave 0 while the others wait.  NW == 1 compiles to exactly the single-wave code (tid == lane, BSYNC == WSYNC).
-template <int NSLOT, int NSOFT, int PATH, int UNI, int NW = 1>
+template <int NSLOT, int NSOFT, int PATH, int UNI, int NW = 1, int LEAN = 1>
 __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, double *sm, const bool want_res = true)
 {
     // want_res = false (wave-uniform): the stationarity residual of the incoming iterate -- an output only (ihm2mpc_get_residuals), a third of
@@ -655,6 +695,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             // over w inside the group on even steps (result: one value per group g) and over g across the groups on odd steps
             // (result: one value per position w), so the output of a step is already laid out as the input of the next:
             //   even: lane holds M[w][g], q_w = Prb_k[w] + p_{k+1}[w] -> p_k[g] ;  odd: lane holds M[g][w], q_g -> p_k[w]
+            if constexpr (LEAN != 0) {
             if (wv == 0) {
                 const int g = lane >> 3, w = lane & 7;
                 double pw = pv[N * 8 + w], pg = 0.0;
@@ -681,6 +722,27 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                             *oo = pw; oo -= 16;
                         }
                     });
+            }
+            } else {
+            if (wv == 0) {
+                const int g = lane >> 3, w = lane & 7;
+                double pw = pv[N * 8 + w], pg = 0.0;
+                stream_rows_v1<-1, 8, 4>(Mg, N, RIC_IDX(w, g), RIC_IDX(g, w),
+                    [&](int k, bool odd, double &prb, double &base) { prb = Prb[k * 8 + (odd ? g : w)]; base = pv[k * 8 + (odd ? w : g)]; },
+                    [&](int k, double m, bool odd, double prb, double base) {
+                        // only the product with the carried value sits on the dependent chain: m * prb and the stage's base term (added
+                        // by ONE lane of each sum) are formed as soon as the operands arrive
+                        if (!odd) {
+                            const double off = fma(m, prb, (w == 0) ? base : 0.0);
+                            pg = sum8(fma(m, pw, off));
+                            if (w == 0) pv[k * 8 + g] = pg;
+                        } else {
+                            const double off = fma(m, prb, (g == 0) ? base : 0.0);
+                            pw = sum_stride8(fma(m, pg, off));
+                            if (g == 0) pv[k * 8 + w] = pw;
+                        }
+                    });
+            }
             }
             BSYNC();
 /*@S:8*/
@@ -712,6 +774,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 /*@S:9*/
             // ---- forward recursion: dx_{k+1} = c_k + M_k dx_k, same alternating register layout ----
             //   even: lane holds M[g][w], dx_k[w] -> dx_{k+1}[g] ;  odd: lane holds M[w][g], dx_k[g] -> dx_{k+1}[w]
+            if constexpr (LEAN != 0) {
             if (wv == 0) {
                 const int g = lane >> 3, w = lane & 7;
                 double dxw = dz[w], dxg = 0.0;
@@ -734,6 +797,24 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                             dz[(k + 1) * 10 + w] = dxw;
                         }
                     });
+            }
+            } else {
+            if (wv == 0) {
+                const int g = lane >> 3, w = lane & 7;
+                double dxw = dz[w], dxg = 0.0;
+                stream_rows_v1<+1, 8, 4>(Mg, N, RIC_IDX(g, w), RIC_IDX(w, g),
+                    [&](int k, bool odd, double &c, double &unused) { c = dz[(k + 1) * 10 + (odd ? w : g)]; unused = 0.0; },
+                    [&](int k, double m, bool odd, double c, double) {
+                        // the affine term rides in ONE lane's product (an fma off the dependent chain's critical add)
+                        if (!odd) {
+                            dxg = sum8(fma(m, dxw, (w == 0) ? c : 0.0));
+                            if (w == 0) dz[(k + 1) * 10 + g] = dxg;
+                        } else {
+                            dxw = sum_stride8(fma(m, dxg, (g == 0) ? c : 0.0));
+                            if (g == 0) dz[(k + 1) * 10 + w] = dxw;
+                        }
+                    });
+            }
             }
             BSYNC();
 /*@S:10*/
@@ -1166,7 +1247,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
                 dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
                 __syncthreads();
             }
-            qp_wave_body<NSLOT, NSOFT, PATH, UNI>(a, b, sm, SQP || step + 1 == s.n_steps);
+            qp_wave_body<NSLOT, NSOFT, PATH, UNI, 1, SQP ? 0 : 1>(a, b, sm, SQP || step + 1 == s.n_steps);
             __syncthreads();
             if (SQP) {
                 const int last = it == n_it - 1;
