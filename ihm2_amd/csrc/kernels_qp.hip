@@ -512,7 +512,13 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             }
             BSYNC();
         };
-        if (exact) multipliers_to_cf();
+        // (LEAN == 0, the SQP instantiations of the persistent loop: the form before -- the multipliers go to LDS in every iteration, inside the
+        // loop below, and the norms are taken in a pass of their own; the leaner form costs THAT kernel 13 % in spilled registers)
+        if (LEAN != 0) { if (exact) multipliers_to_cf(); }
+        else {
+            for (int e = tid; e < NS * NCK; e += NT) cf[e] = 0.0;
+            BSYNC();
+        }
         double mu_acc = 0.0, res_gs = 0.0;
         res_d = 0.0; res_m = 0.0;
 #pragma unroll
@@ -531,8 +537,10 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 res_gs = nanmax(res_gs, fabs(so_rs[q]));
                 mu_acc += so_ls[q] * so_s[q]; res_m = nanmax(res_m, fabs(so_ls[q] * so_s[q]));
             }
+            if (LEAN == 0) SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));
         }
 /*@S:14*/
+        if (LEAN == 0) BSYNC();
         // ---- stationarity and dynamics residuals ----
         // exact: formed from the problem data -- (i) the terms without [A B], g + H z - pi_k - R'(lam_l - lam_u), then (ii) [A B]'pi_{k+1}
         // and r_b from the records.  Otherwise they are what the update at the end of the previous iteration left in rgb / rb: the
@@ -575,12 +583,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             }       // (otherwise gt already holds the followed residual: the update at the end of the previous iteration left it there)
 /*@S:3*/
             res_g = 0.0; res_b = 0.0;
-            if (exact) {
+            if (exact || LEAN == 0) {
                 for (int e = tid; e < NS * 10; e += NT) {
                     const int k = e / 10, j = e % 10;
                     double v = gt[e];
                     if ((k == 0 && j < 8) || (k == N && j >= 8)) { v = 0.0; gt[e] = 0.0; }
-                    rgb[e] = v;          // the residual the update at the end of the iteration carries on
+                    if (exact) rgb[e] = v;          // the residual the update at the end of the iteration carries on
                     res_g = nanmax(res_g, fabs(v));
                 }
                 for (int e = tid; e < N * 8; e += NT) res_b = nanmax(res_b, fabs(rb[e]));
@@ -592,7 +600,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) {
                 if (exact) { qstatus = 0; finished = true; break; }
                 exact = true; exact_mode = true;        // the followed residuals say converged: check against the data
-                multipliers_to_cf();
+                if (LEAN != 0) multipliers_to_cf();
                 continue;
             }
             break;
@@ -969,13 +977,13 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     }
                     const bool masked = (k == 0 && j < 8) || (k == N && j >= 8);
                     const double v = masked ? 0.0 : fma(cp, hdz, cd * ro[q]);
-                    if (e < n10) { rgb[e] = v; gt[e] = v; fol_g = nanmax(fol_g, fabs(v)); }
+                    if (e < n10) { rgb[e] = v; gt[e] = v; if (LEAN != 0) fol_g = nanmax(fol_g, fabs(v)); }
                 }
             }
             for (int e = tid; e < N * 8; e += NT) {
                 const double v = cb * rb[e];
                 rb[e] = v;
-                fol_b = nanmax(fol_b, fabs(v));
+                if (LEAN != 0) fol_b = nanmax(fol_b, fabs(v));
                 const_cast<double *>(linb)[(size_t)(e >> 3) * LIN_REC + RIC_REC_RB + (e & 7)] = v;
             }
         }
