@@ -1255,7 +1255,9 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
                 dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
                 __syncthreads();
             }
-            qp_wave_body<NSLOT, NSOFT, PATH, UNI, 1, SQP ? 0 : 1>(a, b, sm, SQP || step + 1 == s.n_steps);
+            // LEAN (the sweeps and norm phases on a diet): measured per class of instantiation -- it gains 6-8 % in the all-hard RTI loops and costs the
+            // SQP loops 13-17 % and the soft / track-row loops 2-9 % (their register allocation tips into scratch); the stand-alone QP kernels take it
+            qp_wave_body<NSLOT, NSOFT, PATH, UNI, 1, (SQP || NSOFT > 0 || PATH) ? 0 : 1>(a, b, sm, SQP || step + 1 == s.n_steps);
             __syncthreads();
             if (SQP) {
                 const int last = it == n_it - 1;
