@@ -177,7 +177,14 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=(TRACK,), terminal_bound
         ss = solver.get_sqp_stats()
         out["sqp_iter_mean"] = float(ss["sqp_iter"].mean()); out["alpha_mean"] = float(ss["alpha"].mean()); out["alpha_lt1"] = float((ss["alpha"] < 1.0).mean())
     if ranks is not None:
+        # everything that needs this rank's communicator happens BEFORE the solver goes: ihm2mpc_free takes the handle's communicator with it
+        tg0 = time.perf_counter()
         out["gathered"] = ranks.gather_results(solver)
+        out["gather_ms"] = (time.perf_counter() - tg0) * 1e3 if ranks.carrier != "none" else 0.0
+        out["elapsed_max_s"] = ranks.max(el)
+        out["n_ok_sum"] = ranks.sum(n_ok)
+        out["collective"] = ranks.verify(solver)
+        ranks.detach()
     solver.free()
     return out
 
@@ -210,7 +217,14 @@ def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="K
                finished=int(res.finished.sum()), failed=st["failed"], mean_speed=st["mean_speed"],
                progress_m_median=float(np.median(res.x[-1, :, 0] - res.x[0, :, 0])))
     if ranks is not None:
+        tg0 = time.perf_counter()
         out["gathered"] = ranks.gather_results(ctrl.solver)
+        out["gather_ms"] = (time.perf_counter() - tg0) * 1e3 if ranks.carrier != "none" else 0.0
+        out["elapsed_max_s"] = ranks.max(el)
+        for k in ("alive", "finished", "failed"):
+            out[k + "_sum"] = int(ranks.sum(out[k]))
+        out["collective"] = ranks.verify(ctrl.solver)
+        ranks.detach()
     return out
 
 
@@ -315,9 +329,11 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) on a multi-GPU node; gloo only to rehearse the N>1 path on one GPU")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal of every rank (default: LOCAL_RANK); only to rehearse N > 1 on one GPU")
-    ap.add_argument("--native-rccl", action="store_true",
-                    help="barrier / max-reduce / final gather over the C ABI's own RCCL communicator (ihm2mpc_comm_*, no PyTorch) instead of "
-                         "torch.distributed; the RCCL id travels over a TCP socket on MASTER_ADDR")
+    ap.add_argument("--carrier", default="auto", choices=["auto", "rccl", "torch"],
+                    help="who carries the barrier / max-reduce / final gather of N > 1 ranks: rccl = the C ABI's own RCCL communicator "
+                         "(ihm2mpc_comm_*, no PyTorch; the 128-byte RCCL id travels over a TCP socket on MASTER_ADDR), torch = torch.distributed "
+                         "with --dist-backend; auto = rccl on GPUs (backend nccl), torch for the gloo rehearsal")
+    ap.add_argument("--native-rccl", action="store_true", help="the same as --carrier rccl (kept for earlier command lines)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="shard ONE global batch of this many instances over the ranks (contiguous block split, ihm2_amd/dist.py::shard_bounds: "
                          "strong scaling) instead of --batch instances per rank")
@@ -328,6 +344,9 @@ def main():
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and (args.config == 2 or args.live_options):
+        # one-GPU workloads: N processes would each run the whole of it on the same device and print N lines
+        raise SystemExit("--config 2 and --live-options are one-GPU measurements: run them with --gpus 1 (configs 1, 3 and 4 shard over --gpus N)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: bench.py starts one process per GPU itself -- BEFORE anything here touches the GPU -- and rank 0 prints the line.
         # Every rank opens device LOCAL_RANK: on a node with fewer GPUs the rank fails in ihm2mpc_create and so does the run (never a silent
@@ -348,7 +367,7 @@ def main():
         return main_live_options(args)
     from ihm2_amd.dist import RankContext
 
-    ranks = RankContext(carrier="rccl" if args.native_rccl else "auto", backend=args.dist_backend, device=args.device)
+    ranks = RankContext(carrier="rccl" if args.native_rccl else args.carrier, backend=args.dist_backend, device=args.device)
     try:
         if args.config == 3:
             main_config3(args, ranks)
@@ -356,8 +375,10 @@ def main():
             main_config4(args, ranks)
         else:
             main_config1(args, ranks)
-    finally:
-        ranks.close()
+    except BaseException:
+        ranks.abort()          # no barrier on the way out of a failure: the peers are in another collective, or in none (the launcher stops them)
+        raise
+    ranks.close()
 
 
 def main_config1(args, ranks):
@@ -454,6 +475,8 @@ def main_config1(args, ranks):
     u0_all, status_all = ranks.gather_results(solver)          # the final gather of (u0, status) in global order
     gather_ms = (time.perf_counter() - tg0) * 1e3 if world > 1 or ranks.carrier != "none" else 0.0
     assert u0_all.shape == (total, 2) and status_all.shape == (total,)
+    collective = ranks.verify(solver)          # rank count of the communicator + every rank's device: n_gpus = N only if N distinct devices answered
+    ranks.detach()                             # the last exchange is done: the handle's communicator goes before any solver is freed
 
     if rank == 0:
         total_solves = total * steps
@@ -509,7 +532,7 @@ def main_config1(args, ranks):
                                    f"track {TRACK}, closed-loop step = plant + shift/ramp + 1 SQP-RTI iteration + u0 read-back to pinned host memory; "
                                    + ("all steps in one launch, every instance on its own wavefront (ihm2mpc_run_steps)" if persistent else "one launch per phase and step (ihm2mpc_step)"),
                        "batch_per_gpu": B, "global_batch": total, "N": N_H, "M": M_SUB, "parallelism": f"{world} x independent shards",
-                       "collective": ranks.describe()},
+                       "collective": collective},
             "roofline": {"bound": "fp64_valu", "kernel": kname, "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes * B * (steps if persistent else 1),
@@ -520,7 +543,14 @@ def main_config1(args, ranks):
                          "kernel_ms": kms, "linearize_ms": ms_lin, "qp_ms": ms_qp, "n_ipm_mean": n_ipm, "M": M_SUB,
                          "alg_flops_per_solve": f_lin + f_qp,
                          "hbm_fraction_algorithmic": alg_bytes * value / world / 1e9 / HBM_PEAK_GBS,
-                         "hbm_fraction_executed": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
+                         "hbm_fraction_executed": (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         # where the gap is: the two phases of a step as their own kernels (the per-step launches of the latency section below;
+                         # algorithmic flops of the phase / its kernel time / peak), and the executed traffic against the algorithmic bytes
+                         "phases": {"linearize": {"ms": ms_lin, "tflops": f_lin * B / (ms_lin * 1e-3) / 1e12 if ms_lin else None,
+                                                  "frac": f_lin * B / (ms_lin * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ms_lin else None},
+                                    "qp": {"ms": ms_qp, "tflops": f_qp * B / (ms_qp * 1e-3) / 1e12 if ms_qp else None,
+                                           "frac": f_qp * B / (ms_qp * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ms_qp else None}},
+                         "wasted_traffic_ratio": (traffic / (alg_bytes * B * (steps if persistent else 1))) if traffic else None},
             "latency_ms_p50_batch": float(np.percentile(step_ms, 50)), "latency_ms_p99_batch": float(np.percentile(step_ms, 99)),
             "latency_ms_p50_single": float(np.percentile(b1_ms, 50)), "latency_ms_p99_single": float(np.percentile(b1_ms, 99)),
             "status_counts": {str(k): int(v) for k, v in enumerate(np.bincount(status_all, minlength=5)) if v},
@@ -588,8 +618,7 @@ def main_config3(args, ranks):
     kw = dict(terminal_bounds="stage", track_rows="soft", recover=True) if args.model == "fdyn6u" else dict(track_rows="soft")
     r = rti_throughput(model=args.model, B=hi - lo, steps=steps, warmup=warmup, tracks=ALL_TRACKS, device=ranks.device,
                        x0=np.ascontiguousarray(x0_all[lo:hi]), track_id=tid_all[lo:hi], ranks=ranks, **kw)
-    elapsed = ranks.max(r["elapsed_s"])
-    n_ok = ranks.sum(r["n_ok"])
+    elapsed, n_ok = r["elapsed_max_s"], r["n_ok_sum"]
     u0_all, st_all = r["gathered"]
     assert u0_all.shape == (total, 2) and st_all.shape == (total,)
     if ranks.rank == 0:
@@ -600,7 +629,8 @@ def main_config3(args, ranks):
             "config": {"workload": f"configs[3]: global batch {total} dynamic bicycles ({args.model}), instance g on track g mod 7 over {', '.join(ALL_TRACKS)}, N=40, dt=0.05, "
                                    "RK4 x M=25, soft nonlinear track rows 100/100, contiguous block split over the ranks (shard_bounds); launches per phase and step",
                        "batch_per_gpu": hi - lo, "global_batch": total, "N": N_H, "M": M_SUB, "parallelism": f"{ranks.world} x independent shards",
-                       "collective": ranks.describe()},
+                       "collective": r["collective"]},
+            "gather_ms": r["gather_ms"],
             "success_fraction": n_ok / (total * steps),
             "status_counts_last_step": {str(k): int(v) for k, v in enumerate(np.bincount(st_all, minlength=5)) if v},
             "rank0": {k: r[k] for k in _KEEP},
@@ -626,8 +656,8 @@ def main_config4(args, ranks):
     persistent = B <= 1024 and not args.per_step_launches
     r = closed_loop_config5(B=B, steps=steps, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), device_loop=not persistent,
                             persistent=persistent, device=ranks.device, x0=np.ascontiguousarray(x0_all[lo:hi]), ranks=ranks)
-    elapsed = ranks.max(r["wall_s"])
-    alive, finished, failed = (int(ranks.sum(r[k])) for k in ("alive", "finished", "failed"))
+    elapsed = r["elapsed_max_s"]
+    alive, finished, failed = (r[k + "_sum"] for k in ("alive", "finished", "failed"))
     u0_all, st_all = r["gathered"]
     assert u0_all.shape == (total, 2)
     if ranks.rank == 0:
@@ -638,7 +668,8 @@ def main_config4(args, ranks):
             "config": {"workload": f"configs[4]: {total} cars x {steps} control periods, controller = SQP-RTI NMPC (fkin6, N=40, stage terminal box, soft plant-state "
                                    "bounds), plant = kinematic / un-crossed dynamic switch of python/main.py:482-489 (RK4 x 100), freezing rules of python/main.py:326-328,"
                                    "503-504,514-517 on the device; " + ("one launch per car history (ihm2mpc_run_steps)" if persistent else "one ihm2mpc_step per period"),
-                       "batch_per_gpu": B, "global_batch": total, "N": N_H, "parallelism": f"{ranks.world} x independent shards", "collective": ranks.describe()},
+                       "batch_per_gpu": B, "global_batch": total, "N": N_H, "parallelism": f"{ranks.world} x independent shards", "collective": r["collective"]},
+            "gather_ms": r["gather_ms"],
             "cars_alive": alive, "cars_finished": finished, "cars_failed": failed,
             "rank0": {k: r[k] for k in ("control_steps_per_s", "alive", "finished", "failed", "mean_speed", "progress_m_median", "persistent", "B")}}), flush=True)
 

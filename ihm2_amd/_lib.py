@@ -40,6 +40,7 @@ SYMBOLS = {
     "ihm2mpc_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), c_int32_p]),
     "ihm2mpc_comm_allgather_results": (C.c_int, [_H, c_double_p, c_int32_p]),
     "ihm2mpc_comm_allreduce_max": (C.c_int, [_H, c_double_p]),
+    "ihm2mpc_comm_info": (C.c_int, [_H, c_int32_p, C.POINTER(C.c_int64)]),
     "ihm2mpc_comm_free": (C.c_int, [_H]),
     "ihm2mpc_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "ihm2mpc_free": (C.c_int, [_H]),

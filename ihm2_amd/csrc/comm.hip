@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank;
     decltype(&ncclCommInitAll) CommInitAll;
     decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclCommCount) CommCount;
     decltype(&ncclAllGather) AllGather;
     decltype(&ncclAllReduce) AllReduce;
     decltype(&ncclGroupStart) GroupStart;
@@ -36,26 +38,40 @@ struct RcclApi {
     bool ok = false;
 };
 RcclApi rccl;
+std::once_flag rccl_once;
+std::string rccl_err;
+
+// Resolves the entry points once per process (handles may be created from several threads).  A librccl.so the process has already mapped --
+// torch ships its own -- is reused (RTLD_NOLOAD) instead of mapping a second, different RCCL beside it; whatever is opened here keeps its
+// symbols to itself (RTLD_LOCAL).
+void rccl_resolve()
+{
+    void *lib = nullptr;
+    for (const char *name : {"librccl.so", "librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+        if (lib) break;
+    }
+    if (!lib)
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+    if (!lib) { const char *e = dlerror(); rccl_err = std::string("RCCL is not available: ") + (e ? e : "dlopen failed"); return; }
+#define RCCL_SYM(field, sym)                                                             \
+    rccl.field = reinterpret_cast<decltype(rccl.field)>(dlsym(lib, #sym));                \
+    if (!rccl.field) { rccl_err = "librccl.so has no symbol " #sym; return; }
+    RCCL_SYM(GetUniqueId, ncclGetUniqueId) RCCL_SYM(CommInitRank, ncclCommInitRank) RCCL_SYM(CommInitAll, ncclCommInitAll)
+    RCCL_SYM(CommDestroy, ncclCommDestroy) RCCL_SYM(CommCount, ncclCommCount) RCCL_SYM(AllGather, ncclAllGather) RCCL_SYM(AllReduce, ncclAllReduce)
+    RCCL_SYM(GroupStart, ncclGroupStart) RCCL_SYM(GroupEnd, ncclGroupEnd) RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef RCCL_SYM
+    rccl.ok = true;
+}
 
 // 0 = the entry points are there; -1 = librccl.so or one of its symbols is missing (reported through ihm2mpc_last_error)
 int rccl_load()
 {
-    if (rccl.ok) return 0;
-    void *lib = nullptr;
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (lib) break;
-    }
-    if (!lib) return ihm2_fail("RCCL is not available: %s", dlerror());
-#define RCCL_SYM(field, sym)                                                             \
-    rccl.field = reinterpret_cast<decltype(rccl.field)>(dlsym(lib, #sym));                \
-    if (!rccl.field) return ihm2_fail("librccl.so has no symbol %s", #sym)
-    RCCL_SYM(GetUniqueId, ncclGetUniqueId); RCCL_SYM(CommInitRank, ncclCommInitRank); RCCL_SYM(CommInitAll, ncclCommInitAll);
-    RCCL_SYM(CommDestroy, ncclCommDestroy); RCCL_SYM(AllGather, ncclAllGather); RCCL_SYM(AllReduce, ncclAllReduce);
-    RCCL_SYM(GroupStart, ncclGroupStart); RCCL_SYM(GroupEnd, ncclGroupEnd); RCCL_SYM(GetErrorString, ncclGetErrorString);
-#undef RCCL_SYM
-    rccl.ok = true;
-    return 0;
+    std::call_once(rccl_once, rccl_resolve);
+    return rccl.ok ? 0 : ihm2_fail("%s", rccl_err.c_str());
 }
 }  // namespace
 
@@ -85,6 +101,7 @@ struct ihm2mpc_comm {
     int world, rank, Bmax;
     double *send_u, *recv_u, *red;
     int32_t *send_s, *recv_s;
+    long long *ids;                             // (1 + world) device identities of ihm2mpc_comm_info, allocated on first use
     std::vector<int> sizes;
 };
 
@@ -204,7 +221,7 @@ int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint
     HIPC_TRY(hipSetDevice(h->cfg.device));
     ihm2mpc_comm *c = new ihm2mpc_comm();
     c->world = world; c->rank = rank; c->Bmax = 0; c->comm = nullptr;
-    c->send_u = c->recv_u = c->red = nullptr; c->send_s = c->recv_s = nullptr;
+    c->send_u = c->recv_u = c->red = nullptr; c->send_s = c->recv_s = nullptr; c->ids = nullptr;
     c->sizes.assign(sizes, sizes + world);
     for (int r = 0; r < world; r++) c->Bmax = std::max(c->Bmax, (int)sizes[r]);
     ncclUniqueId id;
@@ -259,13 +276,39 @@ int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value)
     return 0;
 }
 
+// What the communicator actually spans, for the record of a multi-GPU run: *count <- ncclCommCount, device_ids (world) <- the PCI identity
+// (domain << 24 | bus << 8 | device) of the device every rank computes on, gathered over the communicator itself -- N ranks on fewer
+// than N devices show up as repeated identities.
+int ihm2mpc_comm_info(ihm2mpc_handle *h, int32_t *count, int64_t *device_ids)
+{
+    if (!h || !h->comm || !count || !device_ids) return ihm2_fail("null argument or no communicator (ihm2mpc_comm_init)");
+    ihm2mpc_comm *c = h->comm;
+    HIPC_TRY(hipSetDevice(h->cfg.device));
+    int n = 0;
+    NCCL_TRY(rccl.CommCount(c->comm, &n));
+    *count = n;
+    int dom = 0, bus = 0, dev = 0;
+    HIPC_TRY(hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->cfg.device));
+    HIPC_TRY(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->cfg.device));
+    HIPC_TRY(hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, h->cfg.device));
+    const long long mine = ((long long)dom << 24) | ((long long)bus << 8) | (long long)dev;
+    if (!c->ids) HIPC_TRY(hipMalloc((void **)&c->ids, (size_t)(1 + c->world) * sizeof(long long)));
+    HIPC_TRY(hipMemcpyAsync(c->ids, &mine, sizeof mine, hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY(rccl.AllGather(c->ids, c->ids + 1, 1, ncclInt64, c->comm, h->stream));
+    std::vector<long long> all(c->world);
+    HIPC_TRY(hipMemcpyAsync(all.data(), c->ids + 1, (size_t)c->world * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPC_TRY(hipStreamSynchronize(h->stream));
+    for (int r = 0; r < c->world; r++) device_ids[r] = all[r];
+    return 0;
+}
+
 int ihm2mpc_comm_free(ihm2mpc_handle *h)
 {
     if (!h || !h->comm) return 0;
     ihm2mpc_comm *c = h->comm;
     (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
-    for (void *p : {(void *)c->send_u, (void *)c->recv_u, (void *)c->send_s, (void *)c->recv_s, (void *)c->red}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)c->send_u, (void *)c->recv_u, (void *)c->send_s, (void *)c->recv_s, (void *)c->red, (void *)c->ids}) if (p) (void)hipFree(p);
     if (c->comm) (void)rccl.CommDestroy(c->comm);
     delete c;
     h->comm = nullptr;

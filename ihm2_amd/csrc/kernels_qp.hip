@@ -596,10 +596,15 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             res_g = nanmax(res_g, res_gs);
             res_g = blk_nanmax(res_g); res_b = blk_nanmax(res_b);
             if (rpass == 0) { res_d = blk_nanmax(res_d); res_m = blk_nanmax(res_m); mu = blk_sum(mu_acc) * inv_m; }
-            if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = 3; finished = true; break; }
-            if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) {
-                if (exact) { qstatus = 0; finished = true; break; }
-                exact = true; exact_mode = true;        // the followed residuals say converged: check against the data
+            // not-a-number in the data of the QP (first pass over them): status 1; a QP that diverges on the way: a failed QP, status 4 --
+            // the same two codes as the reference restatement, wherever the overflow first shows
+            if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { qstatus = (it == 0) ? 3 : 4; finished = true; break; }
+            const bool conv = res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m;
+            if (conv && exact) { qstatus = 0; finished = true; break; }
+            // followed residuals that say "converged" are formed from the data and tested again -- and so are those the iteration limit stops
+            // at: what decides the loose acceptance below, and what ihm2mpc_get_qp_residuals reports, has been checked against A, B and R
+            if ((conv || it >= a.iter_max) && !exact) {
+                exact = true; exact_mode = true;
                 if (LEAN != 0) multipliers_to_cf();
                 continue;
             }

@@ -123,10 +123,36 @@ class NativeComm:
         _lib.check(self.lib.ihm2mpc_comm_allreduce_max(self.solver._h, C.byref(v)))
         return float(v.value)
 
+    def info(self):
+        """``(ncclCommCount, PCI identity of every rank's device)`` -- gathered over the communicator itself."""
+        from . import _lib
+
+        n = C.c_int32(0); ids = (C.c_int64 * self.world)()
+        _lib.check(self.lib.ihm2mpc_comm_info(self.solver._h, C.byref(n), ids))
+        return int(n.value), [int(v) for v in ids]
+
     def free(self):
         from . import _lib
 
-        _lib.check(self.lib.ihm2mpc_comm_free(self.solver._h))
+        if self.solver._h:          # a freed handle has taken its communicator with it (ihm2mpc_free)
+            _lib.check(self.lib.ihm2mpc_comm_free(self.solver._h))
+
+
+def pci_name(ident: int) -> str:
+    """``domain:bus:device`` of a device identity of ``ihm2mpc_comm_info``."""
+    return f"{ident >> 24:04x}:{(ident >> 8) & 0xFFFF:02x}:{ident & 0xFF:02x}"
+
+
+def require_distinct_devices(device_ids, world: int, rehearsal: bool = False) -> int:
+    """A job of ``world`` ranks is reported as ``n_gpus = world`` only if ``world`` distinct devices answered the gather of identities;
+    ``rehearsal`` (all ranks put on one device on purpose: ``bench.py --device D`` / gloo) waives it.  Returns the number of distinct devices."""
+    distinct = len(set(int(d) for d in device_ids))
+    if len(device_ids) != world:
+        raise SystemExit(f"{len(device_ids)} ranks answered, the job has {world}")
+    if distinct != world and not rehearsal:
+        raise SystemExit(f"{world} ranks but {distinct} distinct devices ({', '.join(pci_name(int(d)) for d in device_ids)}): "
+                         "not a {0}-GPU run -- refusing to report n_gpus = {0}".format(world))
+    return distinct
 
 
 class DeviceGroup:
@@ -175,10 +201,13 @@ class RankContext:
         self.addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         self.port = int(os.environ.get("MASTER_PORT", "29500"))
         force = os.environ.get("IHM2_FORCE_DIST") == "1"          # rehearse the exchange path with one rank
+        self.rehearsal = device is not None or backend != "nccl"   # ranks put on one device on purpose / no GPU collective at all
         if self.world == 1 and not force:
             carrier = "none"
         elif carrier == "auto":
-            carrier = "torch"
+            # the product's own RCCL communicator behind the C ABI (no PyTorch) wherever the ranks sit on distinct GPUs; torch.distributed
+            # only where RCCL cannot run (gloo: the rehearsal of N ranks on one device / on the CPU)
+            carrier = "rccl" if backend == "nccl" else "torch"
         self.carrier, self.backend = carrier, backend
         self.on_gpu = backend == "nccl"
         self._dist = None
@@ -267,13 +296,54 @@ class RankContext:
         return {"none": "none (one GPU)", "rccl": "RCCL all-gather of (u0, status) behind the C ABI (ihm2mpc_comm_*, no PyTorch)",
                 "torch": f"torch.distributed ({'nccl = RCCL' if self.on_gpu else 'gloo'}) all_gather of (u0, status)"}[self.carrier]
 
-    def close(self) -> None:
+    def verify(self, solver) -> dict:
+        """What actually answered: the communicator's rank count and every rank's device, gathered over the carrier itself.  Raises
+        ``SystemExit`` when fewer distinct devices than ranks did (unless the run is a declared rehearsal).  The returned record goes
+        into the bench line (``config.collective``)."""
+        rec = {"carrier": self.describe(), "world": self.world}
+        if self._native is not None:
+            count, ids = self._native.info()
+            rec.update(rccl_ranks=count, devices=[pci_name(i) for i in ids], distinct_devices=require_distinct_devices(ids, self.world, self.rehearsal))
+            if count != self.world:
+                raise SystemExit(f"the RCCL communicator spans {count} ranks, the job has {self.world}")
+        elif self._dist is not None:
+            import torch
+
+            t = torch.tensor([float(self.device)], dtype=torch.float64, device="cuda" if self.on_gpu else "cpu")
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            self._dist.all_gather(out, t)
+            ids = [int(o.item()) for o in out]
+            rec.update(devices=[f"local device {i}" for i in ids], distinct_devices=require_distinct_devices(ids, self.world, self.rehearsal))
+            if self.on_gpu:
+                rec["rccl_ranks"] = int(self._dist.get_world_size())
+        else:
+            rec.update(devices=[f"local device {self.device}"], distinct_devices=1)
+        if self.rehearsal and self.world > 1:
+            rec["rehearsal"] = "ranks share a device on purpose (--device / gloo): not a multi-GPU measurement"
+        return rec
+
+    def detach(self) -> None:
+        """Give the solver's communicator back BEFORE the solver is freed (``ihm2mpc_free`` takes the communicator with the handle)."""
         if self._native is not None:
             self._native.allreduce_max(0.0)
             self._native.free(); self._native = None
+
+    def close(self) -> None:
+        self.detach()
         if self._dist is not None:
             self._dist.barrier()
             self._dist.destroy_process_group(); self._dist = None
+
+    def abort(self) -> None:
+        """Leave without synchronising: this rank is unwinding from an error while the others sit in some collective or will never reach a
+        matching one -- a barrier here would turn a failure into a hang.  The launcher stops the peers once this rank has exited."""
+        self._native = None
+        if self._dist is not None:
+            try:
+                self._dist.destroy_process_group()
+            except Exception:
+                pass
+            self._dist = None
 
 
 def spawn_ranks(n: int, argv: list[str], extra_env: dict | None = None) -> int:

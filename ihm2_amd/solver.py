@@ -47,7 +47,7 @@ class BatchedOcpSolver:
         self.ocp = ocp
         self.data: OcpData = ocp.flatten()
         d = self.data
-        self.B, self.N = int(batch_size), d.N
+        self.B, self.N, self.device = int(batch_size), d.N, int(device)
         s_ref = np.atleast_2d(_f64(s_ref)); kappa_ref = np.atleast_2d(_f64(kappa_ref))
         if s_ref.shape != kappa_ref.shape:
             raise ValueError("s_ref and kappa_ref must have the same shape (ntracks, nknots)")

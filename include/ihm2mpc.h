@@ -329,6 +329,9 @@ int ihm2mpc_comm_unique_id(uint8_t *id128);
 int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint8_t *id128, const int32_t *sizes);
 int ihm2mpc_comm_allgather_results(ihm2mpc_handle *h, double *u0_all, int32_t *status_all);      /* host, rank order, on every rank */
 int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value);      /* in place; doubles as a barrier */
+/* what the communicator spans, for the record of a multi-GPU run: *count <- ncclCommCount; device_ids (world) <- the PCI identity
+ * (domain << 24 | bus << 8 | device) of every rank's device, gathered over the communicator: N ranks on fewer than N devices repeat one */
+int ihm2mpc_comm_info(ihm2mpc_handle *h, int32_t *count, int64_t *device_ids);
 int ihm2mpc_comm_free(ihm2mpc_handle *h);
 
 #ifdef __cplusplus

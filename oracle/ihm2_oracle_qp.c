@@ -294,11 +294,14 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
         }
         if (m_act > 0) mu /= m_act;
         if (orc_debug) fprintf(stderr, "ipm it %2d res_g %.3e res_b %.3e res_d %.3e res_m %.3e mu %.3e\n", it, res_g, res_b, res_d, res_m, mu);
-        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { status = 3; break; }
-        if (res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m) {
-            if (exact) { status = 0; break; }
-            exact = 1; exact_mode = 1;      /* the followed residuals say converged: check against the data */
-            goto recompute;
+        /* not-a-number in the QP's data (first pass over them): status 3 (reported as NaN, 1); a QP that diverges on the way: failed, status 4 */
+        if (!(res_g == res_g) || !(res_b == res_b) || !(res_d == res_d) || !(res_m == res_m)) { status = (it == 0) ? 3 : 4; break; }
+        {
+            const int conv = res_g <= tol_g && res_b <= tol_b && res_d <= tol_d && res_m <= tol_m;
+            if (conv && exact) { status = 0; break; }
+            /* followed residuals that say converged are checked against the data -- and so are those the iteration limit stops at: the
+             * loose acceptance below and the reported residuals are then values formed from A, B and R */
+            if ((conv || it >= iter_max) && !exact) { exact = 1; exact_mode = 1; goto recompute; }
         }
         if (it >= iter_max) { status = 1; break; }
 

@@ -43,8 +43,12 @@ class _SqpOpts(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_LIB_PATH):
+    # make decides by the time stamps: a library older than its sources is rebuilt (a stale one once hid a change of the iteration from its own test)
+    try:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    except (OSError, subprocess.CalledProcessError):
+        if force or not os.path.exists(_LIB_PATH):
+            raise
     return _LIB_PATH
 
 

@@ -60,8 +60,10 @@ def main():
     slowest = ranks.max(float(ranks.rank + 1))
     count = ranks.sum(float(B))
     u0_all, st_all = ranks.gather_results(shard)
+    rec = ranks.verify(shard)                          # gloo = a declared rehearsal: ranks may share a device, and the record says so
     if ranks.rank == 0:
-        np.savez(out_path, u0=u0_all, status=st_all, slowest=slowest, count=count, world=ranks.world)
+        np.savez(out_path, u0=u0_all, status=st_all, slowest=slowest, count=count, world=ranks.world, distinct=rec["distinct_devices"],
+                 rehearsal="rehearsal" in rec, n_devices=len(rec["devices"]))
     ranks.close()
 
 

@@ -123,6 +123,8 @@ def test_spawned_ranks_shard_a_non_divisible_batch_and_gather_in_global_order(tm
     assert rc == 0
     got = np.load(out)
     assert int(got["world"]) == world and float(got["slowest"]) == float(world) and float(got["count"]) == float(total)
+    # the record of who answered: three ranks with their device ordinals (LOCAL_RANK), gathered over the carrier; gloo marks the run a rehearsal
+    assert int(got["n_devices"]) == world and int(got["distinct"]) == world and bool(got["rehearsal"])
     plans = [track_table(t) for t in bench.ALL_TRACKS[:3]]
     x0, tid = bench.monte_carlo_batch(plans, total)
     N = 8
@@ -149,3 +151,28 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_a_job_is_reported_as_n_gpus_only_if_n_distinct_devices_answered():
+    """the bench line says ``n_gpus: N`` only if N distinct devices answered the gather of device identities over the
+    communicator (``ihm2mpc_comm_info``); ranks that share a device are refused unless the run is a declared rehearsal."""
+    from ihm2_amd.dist import pci_name, require_distinct_devices
+
+    ids = [(0 << 24) | (b << 8) | 0 for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xE5, 0xF5)]
+    assert require_distinct_devices(ids, 8) == 8
+    assert pci_name(ids[2]) == "0000:65:00"
+    with pytest.raises(SystemExit, match="7 distinct devices"):
+        require_distinct_devices(ids[:7] + ids[:1], 8)                 # two ranks on one device
+    with pytest.raises(SystemExit, match="answered"):
+        require_distinct_devices(ids[:7], 8)                           # a rank is missing
+    assert require_distinct_devices([ids[0]] * 2, 2, rehearsal=True) == 1
+
+
+def test_bench_refuses_one_gpu_workloads_on_several_ranks():
+    """--config 2 and --live-options ignore the world size; with --gpus N > 1 every rank would run the whole workload on one device
+    and print its own line.  Refused before any rank is started."""
+    import subprocess
+
+    for extra in (["--config", "2"], ["--live-options"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra, capture_output=True, text=True)
+        assert r.returncode != 0 and "one-GPU" in r.stderr

@@ -92,9 +92,8 @@ def test_long_closed_loop_stays_with_the_oracle(track):
             yref, yref_e = orc.prepare_step(N, xc, 40.0, x, u)
             out = P.rti_step(x, u, xc, yref, yref_e, pi=pi, lam=lam)
             pi, lam = out["pi"], out["lam"]
-            # a QP that diverges ends as NaN (1) on the GPU and as failed (4) in the oracle: both mean "no step";
-            # such an instance keeps its iterate on both sides and is left out from then on
-            np.testing.assert_array_equal(h["status"][i] == 0, out["status"] == 0)
+            # a failed instance keeps its iterate on both sides and is left out from then on
+            np.testing.assert_array_equal(h["status"][i], out["status"])
             good &= out["status"] == 0
             d = np.maximum(dev(h["u0"][i], u[:, 0]), dev(h["x0"][i], xc))[good]
             assert np.all(d < 3e-4), (chunk, i, float(d.max()))
@@ -157,8 +156,9 @@ def test_config3_dynamic_model_over_all_tracks_matches_oracle(model):
         st = s.solve()
         out = P.rti_step(x, u, x0, yref, yref_e, track_id=tid, pi=pi, lam=lam)
         pi, lam = out["pi"], out["lam"]
-        # failed instances may end as NaN (1) or failed QP (4) on either side; solved ones must agree exactly
-        same = (st == out["status"]) | (np.isin(st, (1, 4)) & np.isin(out["status"], (1, 4)))
+        # one code per outcome on both sides (a diverging QP is a failed QP, 4); the open-loop unstable model as written amplifies rounding
+        # differences until a few marginal QPs converge on one side only
+        same = st == out["status"]
         assert same.mean() >= 0.95, (it, st, out["status"])
         ok = (st == 0) & (out["status"] == 0)
         assert ok.sum() >= (0.3 * B if model == "fdyn6" else 0.8 * B), (it, np.bincount(st, minlength=5))

@@ -57,6 +57,8 @@ def test_native_rccl_communicator_on_one_gpu(track):
     np.testing.assert_array_equal(status, st)
     np.testing.assert_array_equal(u0, s.get_u0())
     assert comm.allreduce_max(3.25) == 3.25
+    count, ids = comm.info()                       # ncclCommCount and the PCI identity of every rank's device, gathered over the communicator
+    assert count == 1 and len(ids) == 1 and ids[0] >= 0
     with pytest.raises(Exception):
         NativeComm(s, B, 1, 0)                     # one communicator per handle
     comm.free()
@@ -65,3 +67,26 @@ def test_native_rccl_communicator_on_one_gpu(track):
     np.testing.assert_array_equal(u0g, u0); np.testing.assert_array_equal(stg, st)
     g.free()
     s.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--config", "3", "--batch", "192", "--steps", "2", "--warmup", "1"],
+                                   ["--config", "4", "--batch", "64", "--steps", "3"],
+                                   ["--batch", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]])
+def test_bench_over_the_native_communicator_with_one_forced_rank(extra):
+    """`bench.py --config 3` over the C ABI's own RCCL communicator used the communicator after `solver.free()` had destroyed it
+    (no JSON line).  One rank with the exchange path forced (IHM2_FORCE_DIST=1): the line is printed and carries the communicator's record."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IHM2_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--carrier", "rccl"] + extra, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    col = line["config"]["collective"]
+    assert col["rccl_ranks"] == 1 and col["distinct_devices"] == 1 and len(col["devices"]) == 1 and "RCCL" in col["carrier"]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "gather_ms" in line

@@ -211,3 +211,35 @@ def test_soft_constraints_match_explicit_slack_formulation():
     ref = minimize(obj, v_ipm, constraints=cons, method="SLSQP", options={"ftol": 1e-14, "maxiter": 200})
     assert ref.fun >= obj(v_ipm) - 1e-6 * (1 + abs(obj(v_ipm)))
     np.testing.assert_allclose(ref.x, v_ipm, rtol=1e-3, atol=1e-3)
+
+
+def test_residuals_reported_at_the_iteration_limit_are_formed_from_the_data(track):
+    """A QP stopped by its iteration limit reports -- and is accepted or rejected on -- residuals formed from A, B, R at the
+    returned point, not the values the iteration carried along between two evaluations.  Late limits are the telling ones:
+    with large barrier weights the carried stationarity residual keeps shrinking (2e-14 after 14 iterations) while the one formed from
+    the data stalls at the rounding error of the Riccati solve (6e-9)."""
+    ocp = make_ocp()
+    P = orc.OracleProblem(ocp.flatten().as_dict(track.s_ref, track.kappa_ref))
+    x0 = sample_x0(track, 4)
+    N = 40
+    for b in range(4):
+        x = np.zeros((N + 1, 8)); u = np.zeros((N, 2)); x[0] = x0[b]
+        for k in range(N):
+            u[k] = [x0[b, 6], x0[b, 7]]
+            x[k + 1] = orc.rk4(0, x[k], u[k], track.s_ref, track.kappa_ref, 0.05, 25)
+        x[:, 1] = np.clip(x[:, 1], -1.5, 1.5)
+        yref = np.zeros((N, 12)); yref[:, 0] = x0[b, 0] + 40.0 * np.arange(N) / N
+        yref_e = np.zeros(8); yref_e[0] = x0[b, 0] + 40.0
+        qp = P.build_qp(x, u, x0[b], yref, yref_e)
+        sg = max(1.0, np.abs(qp["g"]).max())
+        for iter_max in (3, 6, 12, 14):
+            sol = orc.qp_solve(**qp, tol=1e-14, iter_max=iter_max, mu0=0.1, tau0=1.0)
+            assert sol["status"] in (1, 4) and sol["iters"] == iter_max
+            stat, eq, _, _, _ = kkt_report(qp, sol)
+            # (two summation orders: equal to rounding, which is all that is left of the residual at the late limits)
+            assert sol["stats"][0] == pytest.approx(stat, rel=0.02, abs=1e-14 * sg)
+            assert sol["stats"][1] == pytest.approx(eq, rel=0.02, abs=2e-13)
+            Rz = np.einsum("kcj,kj->kc", qp["R"], sol["dz"])
+            t, lam = sol["t"], sol["lam"]
+            fin = np.concatenate([np.isfinite(qp["dl"]), np.isfinite(qp["du"])], 1)
+            assert sol["stats"][3] == pytest.approx(np.abs(lam * t)[fin].max(), rel=1e-9)
