@@ -36,7 +36,10 @@ def test_default_line_carries_the_contract_keys():
 
 def test_bench_starts_its_own_ranks_and_gathers_in_global_order():
     d = _run("--gpus", "2", "--device", "0", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1", "--batch", "96", "--no-cpu-baseline", "--no-extras")
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 192 and "gloo" in d["config"]["collective"]
+    col = d["config"]["collective"]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 192 and "gloo" in col["carrier"]
+    # who answered is part of the line: two ranks on ONE device, accepted only as the declared rehearsal it is
+    assert col["world"] == 2 and len(col["devices"]) == 2 and col["distinct_devices"] == 1 and "rehearsal" in col
     assert sum(d["status_counts"].values()) == 192
     # one global batch, uneven blocks (strong scaling)
     d = _run("--gpus", "2", "--device", "0", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1", "--global-batch", "101", "--no-cpu-baseline", "--no-extras")
