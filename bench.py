@@ -190,14 +190,16 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=(TRACK,), terminal_bound
 
 
 def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="KIN6_DYN6", soft_state_bounds=None, device_loop=False, persistent=False,
-                        device=0, x0=None, ranks=None):
+                        device=0, x0=None, ranks=None, plant_integrator="ERK"):
     """The MiL loop of BASELINE.json configs[4] (new_python/closed_loop_sim.py:34-42, python/main.py:448-517) for B cars on one device."""
     from ihm2_amd.closed_loop_sim import SimModelVariant, Simulator, SimulatorConfig, run_closed_loop, run_closed_loop_device, run_closed_loop_persistent
     from ihm2_amd.controller import IHM2Controller
     from ihm2_amd.track import track_table
 
     plan = track_table(TRACK)
-    ctrl = IHM2Controller(plan.s_ref, plan.kappa_ref, batch_size=B, terminal_bounds=terminal_bounds, soft_state_bounds=soft_state_bounds, device=device)
+    # plant_integrator "IRK": the plants as the reference configures them (python/main.py:395-400: IRK, GAUSS_RADAU_IIA, 4 stages, 100 steps per period)
+    ctrl = IHM2Controller(plan.s_ref, plan.kappa_ref, batch_size=B, terminal_bounds=terminal_bounds, soft_state_bounds=soft_state_bounds, device=device,
+                          sim_integrator_type=plant_integrator)
     sim = Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, num_steps=100), SimModelVariant[plant])
     if x0 is None:
         x0 = sample_x0(plan, B, seed=5)
@@ -212,7 +214,7 @@ def closed_loop_config5(B=4096, steps=200, terminal_bounds="reference", plant="K
         ranks.barrier(ctrl.solver)
     el = time.perf_counter() - t0
     st = res.stats()
-    out = dict(config=5, terminal_bounds=terminal_bounds, plant=plant, soft_state_bounds=soft_state_bounds, device_loop=device_loop, persistent=persistent, B=B,
+    out = dict(config=5, terminal_bounds=terminal_bounds, plant=plant, plant_integrator=plant_integrator, soft_state_bounds=soft_state_bounds, device_loop=device_loop, persistent=persistent, B=B,
                steps=int(res.u.shape[0]), wall_s=el, control_steps_per_s=B * res.u.shape[0] / el, alive=int(res.alive.sum()),
                finished=int(res.finished.sum()), failed=st["failed"], mean_speed=st["mean_speed"],
                progress_m_median=float(np.median(res.x[-1, :, 0] - res.x[0, :, 0])))
@@ -323,6 +325,9 @@ def parse_args(argv=None):
                          "soft nonlinear track rows, as written (fdyn6) and with un-crossed slip angles (fdyn6u); 3 = 65536 dynamic bicycles over "
                          "all data/ tracks, sharded; 4 = MiL closed loop, 4096 cars x 200 steps, sharded")
     ap.add_argument("--model", default="fdyn6u", choices=["fdyn6", "fdyn6u"], help="config 3: the dynamic model (fdyn6 = as written, quirk Q3)")
+    ap.add_argument("--plant-integrator", default="ERK", choices=["ERK", "IRK"],
+                    help="config 4: the plant steps -- ERK = RK4 x 100 per control period, IRK = the reference's own configuration (python/main.py:395-400: "
+                         "IRK, GAUSS_RADAU_IIA, 4 stages, 100 steps)")
     ap.add_argument("--live-options", action="store_true",
                     help="configs[1]'s workload with the solver options the reference runs live (python/main.py:227-238: SQP x 2 iterations, "
                          "MERIT_BACKTRACKING, IRK with 4 Gauss-Legendre stages and 1 step) instead of the metric's SQP_RTI + RK4 x 25; one GPU")
@@ -580,7 +585,9 @@ def main_config1(args, ranks):
 
 def main_config2(args):
     """BASELINE.json configs[2]: batch 8192, dynamic bicycle (Pacejka tyres), N = 40, soft nonlinear track rows, one GPU.
-    Launches per phase and step (the persistent loop has no dynamic-model instantiation).  Both the model as written (quirk Q3:
+    Launches per phase and step: at this batch they beat the one-launch loop of the dynamic models (k_steps<..,DYN=1>, eight rounds of whole
+    histories; measured round 4 with failed instances re-initialised between steps only on this path: 323 k against 292 k solves/s with RK4 x 25,
+    422 k against 368 k with the collocation integrator, profiles/r4/dyn_persistent_vs_perstep.jsonl).  Both the model as written (quirk Q3:
     crossed slip angles, open-loop unstable -- most QPs are infeasible) and the named deviation fdyn6u are run and reported."""
     B = 8192 if args.batch is None else args.batch
     steps = 20 if args.steps is None else min(args.steps, 50)
@@ -655,22 +662,36 @@ def main_config4(args, ranks):
     B = hi - lo
     persistent = B <= 1024 and not args.per_step_launches
     r = closed_loop_config5(B=B, steps=steps, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), device_loop=not persistent,
-                            persistent=persistent, device=ranks.device, x0=np.ascontiguousarray(x0_all[lo:hi]), ranks=ranks)
+                            persistent=persistent, device=ranks.device, x0=np.ascontiguousarray(x0_all[lo:hi]), ranks=ranks, plant_integrator=args.plant_integrator)
     elapsed = r["elapsed_max_s"]
     alive, finished, failed = (r[k + "_sum"] for k in ("alive", "finished", "failed"))
     u0_all, st_all = r["gathered"]
     assert u0_all.shape == (total, 2)
+    as_written = None
+    if ranks.world == 1 and not args.no_extras:
+        # the configuration as the reference writes it -- plant KIN6_DYN6 (crossed slip angles, quirk Q3), reference terminal box, hard boxes --
+        # on a sample of this rank's cars, outside the timed region: what becomes of the cars is part of the line
+        ns = min(B, 256)
+        w = closed_loop_config5(B=ns, steps=steps, terminal_bounds="reference", plant="KIN6_DYN6", soft_state_bounds=None, device_loop=True, device=ranks.device,
+                                x0=np.ascontiguousarray(x0_all[lo:lo + ns]), plant_integrator=args.plant_integrator)
+        as_written = {"cars": ns, "alive": w["alive"], "finished": w["finished"], "failed_or_stopped": ns - w["alive"] - w["finished"], "steps_run": w["steps"],
+                      "control_steps_per_s": w["control_steps_per_s"],
+                      "note": "plant KIN6_DYN6 as written (python/models.py:543-546 feeds every wheel the slip angle of the opposite one: open-loop unstable), "
+                              "reference terminal box, hard state boxes: the reference's stop rule (python/main.py:326-328) ends nearly every run in the first corner"}
+    plant_txt = "RK4 x 100" if args.plant_integrator == "ERK" else "IRK Radau IIA, 4 stages x 100 steps (python/main.py:395-400)"
     if ranks.rank == 0:
         print(json.dumps({
-            "metric": "MiL control steps/s (cars x control periods / wall time), NMPC fkin6 N=40 + plant KIN6_DYN6U (RK4 x 100)",
+            "metric": "MiL control steps/s (cars x control periods / wall time), NMPC fkin6 N=40 + plant KIN6_DYN6U = NAMED DEVIATION from the reference's "
+                      f"KIN6_DYN6 (un-crossed slip angles; stage terminal box; soft plant-state bounds), {plant_txt}",
             "value": total * steps / elapsed, "unit": "control steps/s", "n_gpus": ranks.world, "steps": steps, "warmup": 0, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[4]: {total} cars x {steps} control periods, controller = SQP-RTI NMPC (fkin6, N=40, stage terminal box, soft plant-state "
-                                   "bounds), plant = kinematic / un-crossed dynamic switch of python/main.py:482-489 (RK4 x 100), freezing rules of python/main.py:326-328,"
+                                   f"bounds), plant = kinematic / un-crossed dynamic switch of python/main.py:482-489 ({plant_txt}), freezing rules of python/main.py:326-328,"
                                    "503-504,514-517 on the device; " + ("one launch per car history (ihm2mpc_run_steps)" if persistent else "one ihm2mpc_step per period"),
                        "batch_per_gpu": B, "global_batch": total, "N": N_H, "parallelism": f"{ranks.world} x independent shards", "collective": r["collective"]},
             "gather_ms": r["gather_ms"],
-            "cars_alive": alive, "cars_finished": finished, "cars_failed": failed,
+            "cars_alive": alive, "cars_finished": finished, "cars_failed": failed, "plant_integrator": args.plant_integrator,
+            "reference_configuration_KIN6_DYN6": as_written,
             "rank0": {k: r[k] for k in ("control_steps_per_s", "alive", "finished", "failed", "mean_speed", "progress_m_median", "persistent", "B")}}), flush=True)
 
 

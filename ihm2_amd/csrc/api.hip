@@ -1042,7 +1042,10 @@ int ihm2mpc_run_steps(ihm2mpc_handle *h, int32_t model, int32_t M_sim, double s_
     // The persistent loop pays off while every instance has a wavefront slot of its own (the QP's 40 KB of LDS allow 4 per CU):
     // a larger batch would run in rounds of whole n_steps-long loops, whereas launches per step backfill the slots of finished
     // QPs with the next instances.
-    const bool resident = B <= (size_t)4 * h->n_cu;
+    // (IHM2MPC_PERSISTENT_ROUNDS=1: take the one-launch loop for larger batches too -- the workgroups then run in rounds of whole histories;
+    // measured round 4 against launches per step for the dynamic models, NOTES.md R4)
+    static const bool rounds = [] { const char *e = getenv("IHM2MPC_PERSISTENT_ROUNDS"); return e && e[0] == '1'; }();
+    const bool resident = B <= (size_t)4 * h->n_cu || (rounds && !freeze);
     int rc = 1;
     if (h->cfg.nlp_solver_type == IHM2MPC_SQP && sqp_buffers(h)) return -1;
     if (h->cfg.nlp_solver_type == IHM2MPC_SQP && h->cfg.integrator_type != IHM2MPC_INTEG_ERK && h->sqp_globalization && sqp_phi_buffer(h, nullptr)) return -1;

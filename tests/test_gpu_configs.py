@@ -397,4 +397,19 @@ def test_config4_full_size_closed_loop_and_per_gpu_share():
     per = bench.closed_loop_config5(B=512, persistent=True, **kw)
     assert dev["alive"] + dev["finished"] == 512 and per["alive"] + per["finished"] == 512, (dev, per)
     assert (dev["alive"], dev["finished"], dev["failed"]) == (per["alive"], per["finished"], per["failed"])
+
+
+def test_config4_full_size_with_the_plant_integrator_of_the_reference():
+    """configs[4] with the plants as the reference configures them (python/main.py:395-400: IRK, GAUSS_RADAU_IIA, 4 stages, 100 steps per control
+    period; `bench.py --config 4 --plant-integrator IRK`): the full 4096 cars device-resident and the share of one GPU in one persistent launch
+    (Radau IIA x 100 inside k_steps) -- the same outcome as with RK4 x 100 up to a handful of cars, both runners of the share car by car."""
+    import bench
+
+    kw = dict(steps=200, terminal_bounds="stage", plant="KIN6_DYN6U", soft_state_bounds=(1000.0, 1000.0), plant_integrator="IRK")
+    full = bench.closed_loop_config5(B=4096, device_loop=True, **kw)
+    assert full["steps"] == 200 and full["alive"] + full["finished"] >= 4080, full
+    dev = bench.closed_loop_config5(B=512, device_loop=True, **kw)
+    per = bench.closed_loop_config5(B=512, persistent=True, **kw)
+    assert dev["alive"] + dev["finished"] >= 508 and per["alive"] + per["finished"] >= 508, (dev, per)
+    assert (dev["alive"], dev["finished"], dev["failed"]) == (per["alive"], per["finished"], per["failed"])
     assert abs(dev["progress_m_median"] - per["progress_m_median"]) <= 1e-6 * (1 + abs(dev["progress_m_median"]))
