@@ -983,7 +983,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 const double ratio = (mu > 0.0) ? mu_aff / mu : 0.0;
                 sigma = ratio * ratio * ratio;
             } else {
-                alpha = fmin(1.0, 0.995 * amax); alpha_d = fmin(1.0, 0.995 * amax_d);
+                alpha = fmin(1.0, IHM2MPC_IPM_STEP_FRACTION * amax); alpha_d = fmin(1.0, IHM2MPC_IPM_STEP_FRACTION * amax_d);
             }
             BSYNC();
         }

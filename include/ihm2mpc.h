@@ -66,6 +66,11 @@ extern "C" {
  * python/models.py:543-546, quirk Q3); as written the model is open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s) */
 #define IHM2MPC_MODEL_FDYN6U 2
 
+/* interior-point step: fraction of the distance to the boundary a step may take (primal and dual step lengths separately).  Round 4 tried
+ * 0.9999: -3.6 % iterations in the oracle's closed loop, but instances of the benchmark batch start to fail and GPU / oracle / the two compiler
+ * schedulers drift apart on marginal QPs (six GPU tests); 0.995 stays (NOTES.md R4) */
+#define IHM2MPC_IPM_STEP_FRACTION 0.995
+
 #define IHM2MPC_SQP_RTI 0 /* old/generate.py:21 */
 #define IHM2MPC_SQP 1     /* python/main.py:230 */
 #define IHM2MPC_FIXED_STEP 0         /* full steps */

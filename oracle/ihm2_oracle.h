@@ -46,6 +46,7 @@ enum { ORC_MODEL_FKIN6 = 0, ORC_MODEL_FDYN6 = 1, ORC_MODEL_FDYN6U = 2, ORC_MODEL
  * python/main.py:395-400 (plants: Radau IIA, 100 steps); forward sensitivities by the implicit-function theorem at the final stage values */
 enum { ORC_INTEG_RK4 = 0, ORC_INTEG_IRK_GL4 = 1, ORC_INTEG_IRK_RADAU4 = 2 };
 #define ORC_IRK_NEWTON_ITER 3
+#define ORC_IPM_STEP_FRACTION 0.995 /* fraction of the distance to the boundary an interior-point step may take: the value of IHM2MPC_IPM_STEP_FRACTION (tests/test_cabi.py compares them) */
 
 typedef struct {
     int N;       /* shooting intervals */

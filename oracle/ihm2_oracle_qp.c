@@ -376,7 +376,7 @@ int orc_qp_solve_soft(int N, const double *H, const double *g, const double *A, 
                 memcpy(dlams_a, dlams, sizeof(double) * NI); memcpy(ds_a, ds, sizeof(double) * NI);
                 if (m_act == 0) { alpha = alpha_d = 1.0; break; } /* no inequalities: Newton step is exact */
             } else {
-                alpha = fmin(1.0, 0.995 * amax); alpha_d = fmin(1.0, 0.995 * amax_d);
+                alpha = fmin(1.0, ORC_IPM_STEP_FRACTION * amax); alpha_d = fmin(1.0, ORC_IPM_STEP_FRACTION * amax_d);
             }
         }
         if (orc_debug) fprintf(stderr, "        sigma %.3e alpha %.6f alpha_d %.6f\n", sigma, alpha, alpha_d);

@@ -71,3 +71,16 @@ def test_lean_trig_functions_of_the_models_match_libm(tmp_path):
     for c in ("6.36619772367581382433e-01", "1.57079632679489655800e+00", "6.12323399573676603587e-17", "-1.49738490485916983693e-33",
               "1.58969099521155010221e-10", "-1.13596475577881948265e-11"):
         assert c in hdr and c in open(src).read()
+
+
+def test_oracle_and_library_share_the_interior_point_constants():
+    """The checker and the product define the algorithm's constants independently (the product never includes anything under oracle/): same values."""
+    import re
+
+    def define(path, name):
+        m = re.search(r"#define\s+%s\s+([0-9.eE+-]+)" % name, open(os.path.join(ROOT, path)).read())
+        assert m, (path, name)
+        return float(m.group(1))
+
+    assert define("include/ihm2mpc.h", "IHM2MPC_IPM_STEP_FRACTION") == define("oracle/ihm2_oracle.h", "ORC_IPM_STEP_FRACTION")
+    assert define("include/ihm2mpc.h", "IHM2MPC_IRK_NEWTON_ITER") == define("oracle/ihm2_oracle.h", "ORC_IRK_NEWTON_ITER")

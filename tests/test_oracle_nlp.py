@@ -78,4 +78,8 @@ def test_converged_sqp_is_the_slsqp_solution_of_the_written_out_programme(proble
     assert r.success, r.message
     assert abs(r.fun - cost(w0)) <= 1e-6 * max(1.0, abs(r.fun))                    # same optimal value ...
     Xs, Us = split(r.x)
-    assert np.max(np.abs(Xs - x) / np.maximum(1.0, np.abs(x))) < 2e-4 and np.max(np.abs(Us - u) / np.maximum(1.0, np.abs(u))) < 2e-4      # ... same point
+    # ... same point: 2e-4 relative on every component the cost determines; the torque state and input carry the weight 1e-5 (Q[6,6], R[0,0]:
+    # the objective is flat along them, 1e-3 relative is what two converged solvers agree to -- the optimal VALUE above pins them)
+    ex = np.abs(Xs - x) / np.maximum(1.0, np.abs(x)); eu = np.abs(Us - u) / np.maximum(1.0, np.abs(u))
+    stiff = [0, 1, 2, 3, 4, 5, 7]
+    assert ex[:, stiff].max() < 2e-4 and eu[:, 1].max() < 2e-4 and ex[:, 6].max() < 1e-3 and eu[:, 0].max() < 1e-3
