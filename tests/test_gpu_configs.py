@@ -346,8 +346,9 @@ def test_both_builds_agree_on_4096_instances(track, kind):
             ok = st == 0
             assert ok.mean() > 0.95
             # (two summation orders of the barrier parameter: one marginal convergence test in a few thousand may fall the other way)
-            assert np.mean(r["it"][ok] == out["qp_iter"][ok]) >= 0.999 and np.max(np.abs(r["it"][ok] - out["qp_iter"][ok])) <= 1
-            assert _rel(r["u"][ok], u[ok]) < 1e-6                                         # tolerance 1e-6 relative
+            same = r["it"] == out["qp_iter"]
+            assert np.mean(same[ok]) >= 0.999 and np.max(np.abs(r["it"][ok] - out["qp_iter"][ok])) <= 1
+            assert _rel(r["u"][ok & same], u[ok & same]) < 1e-6                           # tolerance 1e-6 relative (where both sides stopped at the same iterate)
         s.set_lap_wrap(True)
         h = s.run_steps(40.0, 4, model=0, M_sim=25, u0_hist=True, status_hist=True, qp_iter_hist=True)
         r.update(h_u0=h["u0"].copy(), h_st=h["status"].copy(), h_it=h["qp_iter"].copy())
