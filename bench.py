@@ -38,7 +38,7 @@ ALL_TRACKS = ("acceleration", "fsds_competition_1", "fsds_competition_2", "fsds_
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector peak = fp64 matrix peak (guide: MI355X_MICROARCH.md / SURVEY.md 8d)
 HBM_PEAK_GBS = 8000.0
 CONFIG3_TOTAL, CONFIG4_TOTAL, NODE_GPUS = 65536, 4096, 8
-TRAFFIC_JSON = os.path.join("profiles", "r3", "bench_traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r4", "bench_traffic.json")
 
 
 def build_problem(batch):
@@ -503,7 +503,7 @@ def main_config1(args, ranks):
         # process; the per-solve figure comes from the committed rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 5`
         # (profiles/r*/bench_traffic.json, corrected as MI355X_MICROARCH.md prescribes) and is scaled by the solves of this launch
         traffic, traffic_src = None, None
-        for cand in (TRAFFIC_JSON, os.path.join("profiles", "r2", "bench_traffic.json")):
+        for cand in (TRAFFIC_JSON, os.path.join("profiles", "r3", "bench_traffic.json")):
             try:
                 tj = json.load(open(os.path.join(ROOT, cand)))
                 key = "k_steps" if persistent else kname

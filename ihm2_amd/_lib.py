@@ -86,7 +86,6 @@ SYMBOLS = {
     "ihm2mpc_get_slacks": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_slacks": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_get_timings": (C.c_int, [_H, c_double_p, C.c_int32]),
-    "ihm2mpc_set_tail_fraction": (C.c_int, [_H, C.c_double]),
     "ihm2mpc_set_x0_device": (C.c_int, [_H, C.c_void_p]),
     "ihm2mpc_get_u0_device": (C.c_int, [_H, C.c_void_p]),
     "ihm2mpc_get_x_device": (C.c_int, [_H, C.c_void_p]),

@@ -154,7 +154,6 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     h->NS = cfg->N + 1;
     h->n_cu = prop.multiProcessorCount;
     { const char *e = getenv("IHM2MPC_BLOCK_QP"); h->block_qp = !(e && e[0] == '0'); }
-    { const char *e = getenv("IHM2MPC_TAIL_FRACTION"); h->tail_fraction = e ? atof(e) : 0.0;      /* off by default: measured round 4, it does not pay on 20-step launches (NOTES.md R4) */ if (!(h->tail_fraction >= 0.0 && h->tail_fraction < 1.0)) h->tail_fraction = 0.0; }
     const size_t B = h->B, N = h->N, NS = h->NS;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -201,7 +200,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->tail_ho, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_rg, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc, h->ls_pending, h->irk_tab, h->sim_irk_tab,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
@@ -789,24 +788,6 @@ int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n)
     HIP_TRY(hipEventElapsedTime(&t_total, h->ev[0], h->ev[2]));
     HIP_TRY(hipEventElapsedTime(&t_qp, h->ev[1], h->ev[2]));
     ms[0] = t_total; ms[2] = t_qp; ms[1] = t_total - t_qp;
-    if (n >= 4) {       // instances the last persistent launch handed over to the four-wave tail kernel
-        int32_t cnt[3] = {0, 0, 0};
-        if (h->tail_ho) {
-            HIP_TRY(hipMemcpyAsync(cnt, h->tail_ho, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-        }
-        ms[3] = cnt[1];
-    }
-    return 0;
-}
-
-// share of the batch that has to be through its steps before a persistent launch hands its stragglers to the four-wave tail kernel
-// (k_steps_tail, kernels_qp.hip); 0 = no hand-over.  Results do not depend on it (bit-identical), only the duration of the launch does.
-int ihm2mpc_set_tail_fraction(ihm2mpc_handle *h, double fraction)
-{
-    CHECK_H(h);
-    if (!(fraction >= 0.0 && fraction < 1.0)) return fail("the tail fraction must lie in [0, 1)");
-    h->tail_fraction = fraction;
     return 0;
 }
 

@@ -57,9 +57,6 @@ struct ihm2mpc_handle {
     double *slot_lb_blk, *slot_ub_blk;
     int nslot_lane_blk;            // 0: no such table (soft sides present)
     bool block_qp;                 // use k_qp_block for batches of at most one instance per CU (IHM2MPC_BLOCK_QP=0 turns it off)
-    double tail_fraction;          // persistent loop: share of the batch that has to be through before the stragglers are handed to the four-wave
-                                   // tail kernel (k_steps_tail); 0 = no hand-over (IHM2MPC_TAIL_FRACTION)
-    int32_t *tail_ho;              // counters and lists of the hand-over (3 + 2 B), allocated on first use
     double *slot_lb, *slot_ub;     // raw bounds, +-inf if that side is absent (soft slots are one-sided)
     double *slot_zw, *slot_Zw;     // slack cost zw s + 1/2 Zw s^2 of a soft slot; Zw < 0 = hard slot
     // host copies the table is rebuilt from (set_bounds / set_soft may come in either order)

@@ -1183,10 +1183,6 @@ struct StepArgs {
     int32_t *hist_st, *hist_it;             // (n_steps,B) or nullptr
     const IrkTab *irk_tab;                  // IRK = 1: the tableau of the shooting intervals' collocation step, in device memory
     const IrkTab *sim_irk_tab;              // plant steps by collocation (python/main.py:395-400: Radau IIA x M_sim) instead of RK4 x M_sim; nullptr: RK4
-    // hand-over of the launch's stragglers (nullptr: none): once ho_threshold instances have done all their steps, a wave that reaches a step
-    // boundary leaves -- its instance and the step it stopped at go on the list k_steps_tail (four waves per instance on the freed CUs) works off
-    int32_t *ho;                            // [0] instances done, [1] instances on the list, [2] next list entry k_steps_tail takes; then (B) list, (B) resume step
-    int ho_threshold;
 };
 
 // SQP = 0: one RTI iteration per step (the SQP code is compiled out: next to the QP body it changed the register allocation of
@@ -1219,15 +1215,6 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
         }
     };
     for (int step = 0; step < s.n_steps; step++) {
-        if (s.ho) {        // enough instances are through: this one goes to the tail kernel (wave-uniform: every lane loads the same counter)
-            if (__hip_atomic_load(s.ho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= s.ho_threshold) {
-                if (lane == 0) {
-                    const int idx = atomicAdd(s.ho + 1, 1);
-                    s.ho[3 + idx] = b; s.ho[3 + B + b] = step;
-                }
-                return;
-            }
-        }
         // wave-uniform: is this car still driving?  (freeze: a failed solve stops it, python/main.py:326-328)
         bool act = s.active ? s.active[b] != 0 : true;
         if (s.freeze && act) {
@@ -1331,66 +1318,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
             __syncthreads();
         }
     }
-    if (s.ho && lane == 0) atomicAdd(s.ho, 1);
 }
-
-// ---- the tail of a persistent launch: FOUR wavefronts per instance ----
-// A launch of k_steps ends with its slowest instance (240 interior-point iterations over 20 steps where the mean is 181) while the SIMDs of
-// the instances that are through sit idle.  With the hand-over armed (StepArgs.ho) the stragglers leave k_steps at a step boundary once most of
-// the batch is done, and this kernel -- one workgroup of four waves per CU, launched behind it on the same stream -- works their remaining
-// steps off the list: the QP with its lane-parallel phases on 256 lanes (qp_wave_body<.., NW = 4>, 0.38 against 0.95 ms per solve), plant,
-// shift and linearisation on wave 0 with the code of k_steps.  The slot sums of the four-wave body are taken in the order of the 64-lane
-// table, so the results are BIT-IDENTICAL to a launch without the hand-over (tests/test_gpu_closed_loop.py).
-#if QP_SET == 0
-template <int NSLOT_BLK, int UNI>
-__global__ __launch_bounds__(256) void k_steps_tail(const StepArgs *sp, QpArgs a)
-{
-    const StepArgs &s = *sp;
-    extern __shared__ double sm[];
-    __shared__ int s_idx;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int N = a.N;
-    const size_t B = a.B;
-    for (;;) {
-        if (tid == 0) s_idx = atomicAdd(s.ho + 2, 1);
-        __syncthreads();
-        const int idx = s_idx;
-        __syncthreads();
-        if (idx >= s.ho[1]) return;             // (the list is complete: k_steps has ended)
-        const int b = s.ho[3 + idx];
-        for (int step = s.ho[3 + B + b]; step < s.n_steps; step++) {
-            if (s.lap_wrap) { if (wv == 0) dev_wrap_lap(b, lane, N, s.nknots, s.s_ref, a.track_id, s.x0, a.x); __syncthreads(); }
-            // warm-start shift: the device function synchronises the block between its reads and writes, so all four waves go through it
-            // (each does the same copies)
-            dev_prepare(b, lane, N, s.s_target, 2, s.x0, a.x, a.u, s.yref, s.yref_e);
-            __syncthreads();
-            if (wv == 0) {
-                // linearisation on the lanes 0 .. N-1, the kinematic plant (the OCP's own model on (x0, u0)) on lane N: as k_steps
-                const int trk = a.track_id[b];
-                double *spare = s.lin + (size_t)B * N * LIN_REC;
-                for (int k = lane; k < N + 1; k += 64) {
-                    const bool plant = k == N;
-                    const double *xk = plant ? s.x0 + (size_t)b * 8 : a.x + ((size_t)b * (N + 1) + k) * 8;
-                    const double *uk = plant ? a.u0 + (size_t)b * 2 : a.u + ((size_t)b * N + k) * 2;
-                    double *rec = plant ? spare + (size_t)b * LIN_REC : s.lin + ((size_t)b * N + k) * LIN_REC;
-                    call_integrate_fkin6(xk, uk, plant ? xk : xk + 8, trk, plant ? s.M_sim : s.M, s.dt, s.nknots, s.s_ref, s.kappa_ref, rec,
-                                         plant ? s.x0 + (size_t)b * 8 : nullptr);
-                }
-            }
-            __syncthreads();
-            if (wv == 0) dev_prepare(b, lane, N, s.s_target, 1, s.x0, a.x, a.u, s.yref, s.yref_e);      // reference ramp from the new x0
-            __syncthreads();
-            qp_wave_body<NSLOT_BLK, 0, 0, UNI, 4, 1>(a, b, sm, step + 1 == s.n_steps);
-            __syncthreads();
-            if (s.hist_u0 && tid < 2) s.hist_u0[((size_t)step * B + b) * 2 + tid] = a.u0[(size_t)b * 2 + tid];
-            if (s.hist_x0 && tid < 8) s.hist_x0[((size_t)step * B + b) * 8 + tid] = s.x0[(size_t)b * 8 + tid];
-            if (s.hist_st && tid == 0) s.hist_st[(size_t)step * B + b] = a.status[b];
-            if (s.hist_it && tid == 0) s.hist_it[(size_t)step * B + b] = a.qp_iter[b];
-        }
-        __syncthreads();
-    }
-}
-#endif
 
 }  // namespace
 
@@ -1479,19 +1407,6 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
     s.hist_u0 = hist_u0; s.hist_x0 = hist_x0; s.hist_st = hist_st; s.hist_it = hist_it;
     s.irk_tab = (const IrkTab *)h->irk_tab;
     s.sim_irk_tab = irk_plant ? (const IrkTab *)h->sim_irk_tab : nullptr;
-    s.ho = nullptr; s.ho_threshold = 0;
-#if QP_SET == 0
-    // hand-over of the stragglers to k_steps_tail: the all-hard RTI loop with the kinematic plant riding on the linearisation (the benchmarked
-    // configuration), a batch that fills the chip, no per-car stop rules
-    const bool tail = hard && (h->uniform_H && h->uniform_CD) && !sqp && !irk && !irk_plant && !dyn && !freeze && !s.active && model == IHM2MPC_MODEL_FKIN6 && h->tail_fraction > 0.0 &&
-                      h->nslot_lane_blk >= 1 && h->nslot_lane_blk <= 2 && h->B >= 2 * h->n_cu && n_steps >= 2 && h->nslot_lane * 64 <= (h->N + 1) * 12;
-    if (tail) {
-        if (!h->tail_ho && hipMalloc((void **)&h->tail_ho, (3 + 2 * (size_t)h->B) * sizeof(int32_t)) != hipSuccess) return 1;
-        if (hipMemsetAsync(h->tail_ho, 0, 3 * sizeof(int32_t), h->stream) != hipSuccess) return 1;
-        s.ho = h->tail_ho;
-        s.ho_threshold = std::max(1, std::min(h->B - 1, (int)(h->tail_fraction * h->B)));
-    }
-#endif
     // every field of s is set: upload it (and the line search's block in the SQP mode)
     static_assert(sizeof(StepArgs) <= 32 * sizeof(double), "step_args holds 256 bytes");
     static_assert(sizeof(LsArgs) <= 64 * sizeof(double), "ls_args holds 512 bytes");
@@ -1536,31 +1451,6 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
     if (hard) {
         if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 0, 0, 1); else LAUNCH_STEPS(5, 0, 0, 0); }
         else { if (uni) LAUNCH_STEPS(8, 0, 0, 1); else LAUNCH_STEPS(8, 0, 0, 0); }
-    }
-#endif
-#if QP_SET == 0
-    if (tail) {        // behind the loop on the same stream: one workgroup per CU takes the instances the loop handed over, one after the other
-        QpArgs at = a;
-        at.slot_kc = h->slot_kc_blk; at.slot_lb = h->slot_lb_blk; at.slot_ub = h->slot_ub_blk; at.nslots = h->nslot_lane_blk * 256;
-        (void)hipFuncSetAttribute((const void *)k_steps_tail<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_steps_tail<2, 1>), dim3(h->n_cu), dim3(256), lds, h->stream, sdev, at);
-    }
-#endif
-#if QP_SET != 0
-    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them)
-    if (!hard) {
-        if (!uni) return 1;
-        const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
-        if (!h->path_on) {
-            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 0, 1);
-            else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0, 1);
-            else return 1;
-        } else {
-            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 1, 1);
-            else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS(8, 3, 1, 1);
-            else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 1, 1);
-            else return 1;
-        }
     }
 #endif
 #undef LAUNCH_STEPS

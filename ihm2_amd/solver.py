@@ -349,14 +349,9 @@ class BatchedOcpSolver:
         return out
 
     def get_timings(self):
-        ms = np.zeros(4)
-        _lib.check(self.lib.ihm2mpc_get_timings(self._h, _ptr(ms), 4))
-        return {"total_ms": ms[0], "linearize_ms": ms[1], "qp_ms": ms[2], "tail_instances": int(ms[3])}
-
-    def set_tail_fraction(self, fraction: float):
-        """Share of the batch that has to be through its steps before ``run_steps`` hands the stragglers of its launch to four wavefronts each
-        (0 = never).  Changes the duration of the launch, not its results."""
-        _lib.check(self.lib.ihm2mpc_set_tail_fraction(self._h, float(fraction)))
+        ms = np.zeros(3)
+        _lib.check(self.lib.ihm2mpc_get_timings(self._h, _ptr(ms), 3))
+        return {"total_ms": ms[0], "linearize_ms": ms[1], "qp_ms": ms[2]}
 
     # ---- device-pointer variants (zero copy; dptr = integer device address, instance-major layout) ----
     def set_x0_device(self, dptr: int):

@@ -220,14 +220,8 @@ int ihm2mpc_get_multipliers(ihm2mpc_handle *h, double *pi, double *lam);
 /* slack values the next SQP-mode solve starts from (its line search walks from them to the QP's); NULL = zeros */
 int ihm2mpc_set_slacks(ihm2mpc_handle *h, const double *sl);     /* (B,N+1,28) */
 int ihm2mpc_get_slacks(ihm2mpc_handle *h, double *sl);         /* (B,N+1,28) slack of each soft side after the last QP */
-/* milliseconds of the last solve(): [0] total, [1] linearize, [2] qp+update (HIP events); n >= 4: [3] instances the last ihm2mpc_run_steps
- * handed to its four-wave tail kernel */
+/* milliseconds of the last solve(): [0] total, [1] linearize, [2] qp+update (HIP events) */
 int ihm2mpc_get_timings(ihm2mpc_handle *h, double *ms, int32_t n);
-/* ihm2mpc_run_steps in one launch ends with its slowest instance; once this share of the batch is through its steps, the others leave the loop
- * at their next step boundary and are finished by four wavefronts each on the freed compute units.  Same results bit for bit; 0 = off, which
- * is the default (environment IHM2MPC_TAIL_FRACTION at create): measured on the bench workload it costs 2-8 % (the stragglers' surplus is under
- * three steps, the hand-over works in whole steps and four waves are only twice as fast as one).  No counterpart in the reference. */
-int ihm2mpc_set_tail_fraction(ihm2mpc_handle *h, double fraction);
 
 /* ---- device-pointer variants (zero-copy closed loop, RCCL gather of results) ----
  * dptr is device memory on the handle's device, SAME (instance-major) layout as the host variant */

@@ -510,34 +510,3 @@ def test_mil_loop_as_the_reference_configures_it(track, monkeypatch):
     with pytest.raises(ValueError, match="sim_integrator_type"):
         Simulator(ctrl, SimulatorConfig(sampling_time=ctrl.dt, integrator_type="IRK"), SimModelVariant.KIN6)
     ctrl.solver.free()
-
-
-@pytest.mark.parametrize("n_max,fraction", [(2.0, 0.5), (0.9, 0.3), (2.0, 0.9)])
-def test_tail_hand_over_gives_the_same_launch_bit_for_bit(track, n_max, fraction):
-    """a persistent launch ends with its slowest instance.  With the hand-over armed, the instances that are not through when
-    `fraction` of the batch is leave the loop at a step boundary and are finished by four wavefronts each (k_steps_tail) -- on the same data, with
-    the slot sums of the interior-point iteration taken in the order of the one-wave body: histories, iterates and multipliers are those of a
-    launch without the hand-over, BIT FOR BIT, for both all-hard slot tables (n_max 0.9: eight slots per lane)."""
-    from ihm2_amd.solver import BatchedOcpSolver
-
-    B, steps = 1024, 14
-    x0 = sample_x0(track, B, seed=77)
-    res = []
-    for frac in (0.0, fraction):
-        s = BatchedOcpSolver(make_ocp(n_max=n_max), B, track.s_ref, track.kappa_ref)
-        s.set_tail_fraction(frac)
-        s.set_lap_wrap(True)
-        s.set_x0(x0); s.init_guess()
-        s.step(40.0, model=0, M_sim=25)
-        h = s.run_steps(40.0, steps, model=0, M_sim=25, u0_hist=True, x0_hist=True, status_hist=True, qp_iter_hist=True)
-        s.synchronize()
-        res.append((h, s.get_x(), s.get_u(), s.get_multipliers(), s.get_residuals(), s.get_qp_residuals(), s.get_timings()["tail_instances"]))
-        s.free()
-    (ha, xa, ua, ma, ra, qa, na), (hb, xb, ub, mb, rb, qb, nb) = res
-    assert na == 0 and 0 < nb <= B - int(fraction * B), (na, nb)          # the hand-over happened, for at most the share it was allowed
-    for k in ("status", "qp_iter", "x0", "u0"):
-        np.testing.assert_array_equal(ha[k], hb[k])
-    np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ua, ub)
-    np.testing.assert_array_equal(ma[0], mb[0]); np.testing.assert_array_equal(ma[1], mb[1])
-    np.testing.assert_array_equal(ra, rb); np.testing.assert_array_equal(qa, qb)
-    assert (ha["status"] == 0).mean() > 0.95
