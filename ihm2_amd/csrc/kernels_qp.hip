@@ -1453,6 +1453,23 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
         else { if (uni) LAUNCH_STEPS(8, 0, 0, 1); else LAUNCH_STEPS(8, 0, 0, 0); }
     }
 #endif
+#if QP_SET != 0
+    // the soft / track-row tables: batch-shared Hessians and rows only (the reference's OCP has them)
+    if (!hard) {
+        if (!uni) return 1;
+        const int per_lane = h->nslot_lane, nsoft = h->nsoft_lane;
+        if (!h->path_on) {
+            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 0, 1);
+            else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0, 1);
+            else return 1;
+        } else {
+            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 1, 1);
+            else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS(8, 3, 1, 1);
+            else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 1, 1);
+            else return 1;
+        }
+    }
+#endif
 #undef LAUNCH_STEPS
 #undef LAUNCH_K
     return 0;
