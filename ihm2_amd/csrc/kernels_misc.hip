@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
                                                    const double *__restrict__ lg, const double *__restrict__ ug,
                                                    double *__restrict__ xs, double *__restrict__ us,
                                                    const int32_t *__restrict__ only_failed, double *__restrict__ pi,
-                                                   double *__restrict__ lam)
+                                                   double *__restrict__ lam, int exact_lags)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
@@ -59,6 +59,10 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
     TrackSeg trk;
     trk.init(s_ref + (size_t)tid * nknots, kappa_ref + (size_t)tid * nknots, nknots, x[0]);
     const double h = dt / M;
+    // exact_lags (the recovery of failed instances, a guess the next RTI step corrects): the two actuator states are linear lags on a constant input
+    // (python/models.py:251-252) -- taken in closed form at the stage times, so that the sub-step is chosen for the vehicle's dynamics (12.5 ms) and not
+    // for the 1 ms torque lag that forces RK4 to 25 sub-steps per interval: a sixth of the model evaluations of a rollout the whole batch waits for
+    const double eT2 = exact_lags ? exp(-0.5 * h / k_tT) : 1.0, eT = eT2 * eT2, eD2 = exact_lags ? exp(-0.5 * h / k_tdelta) : 1.0, eD = eD2 * eD2;
     double J[8][10];
     double *xb = xs + (size_t)b * (N + 1) * 8, *ub = us + (size_t)b * N * 2;
     for (int k = 0; k < N; k++) {
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
             double xacc[8], K[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) { xacc[i] = x[i]; K[i] = 0.0; }
+            const double dT0 = x[6] - u_T, dD0 = x[7] - u_d;
 #pragma unroll 1
             for (int st = 0; st < 4; st++) {
                 const double ah = (st == 0) ? 0.0 : ((st == 3) ? h : 0.5 * h);
@@ -86,6 +91,10 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
                 double X[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
+                if (exact_lags) {
+                    X[6] = fma(dT0, (st == 0) ? 1.0 : ((st == 3) ? eT : eT2), u_T);
+                    X[7] = fma(dD0, (st == 0) ? 1.0 : ((st == 3) ? eD : eD2), u_d);
+                }
                 if (MODEL == IHM2MPC_MODEL_FDYN6U) fdyn6_eval<false, true>(X, u_T, u_d, trk, K, J);
                 else fkin6_eval<false>(X, u_T, u_d, trk, K, J);
 #pragma unroll
@@ -93,6 +102,7 @@ __global__ __launch_bounds__(64) void k_init_guess(int B, int N, int M, double d
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) x[i] = xacc[i];
+            if (exact_lags) { x[6] = fma(dT0, eT, u_T); x[7] = fma(dD0, eD, u_d); }
         }
     }
 #pragma unroll
@@ -118,11 +128,16 @@ void ihm2_launch_init_guess(ihm2mpc_handle *h, double v_ref_scale, int only_fail
     // the rollout is an RK4 rollout whatever the OCP's integrator: with IRK (one step per interval) it takes the 25 sub-steps RK4 needs
     // on the actuator lags (a guess: the first linearisation sees its defects against the OCP's own discretisation)
     // (sub-steps of at most 2 ms: RK4 is stable on the 1 ms torque lag up to 2.78 ms -- a longer interval takes more of them)
-    const int M_roll = (h->cfg.integrator_type == IHM2MPC_INTEG_ERK) ? h->cfg.M : std::max(25, (int)std::ceil(h->cfg.dt / 2e-3));
+    int M_roll = (h->cfg.integrator_type == IHM2MPC_INTEG_ERK) ? h->cfg.M : std::max(25, (int)std::ceil(h->cfg.dt / 2e-3));
+    // recovery (ihm2mpc_reinit_failed; no counterpart in the reference, whose loop stops at the first bad status, python/main.py:326-328): the whole batch
+    // waits for the rollouts of its few failed instances -- 3.3 ms of a 19-26 ms step of configs[2] with 25 sub-steps per interval -- so they take the
+    // actuator lags in closed form and sub-steps of at most 12.5 ms (0.55 ms)
+    const int exact_lags = only_failed ? 1 : 0;
+    if (exact_lags) M_roll = std::max(4, (int)std::ceil(h->cfg.dt / 12.5e-3));
 #define LAUNCH_IG(MD)                                                                                                          \
     hipLaunchKernelGGL(k_init_guess<MD>, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->B, h->N, M_roll, h->cfg.dt,      \
                        v_ref_scale, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x0, h->lbu, h->ubu, h->lg, h->ug,    \
-                       h->x, h->u, mask, h->pi, h->lam)
+                       h->x, h->u, mask, h->pi, h->lam, exact_lags)
     // recovery of a few failed instances: the kinematic rollout is 5x cheaper and its defects are what one RTI step absorbs
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U && !only_failed) LAUNCH_IG(IHM2MPC_MODEL_FDYN6U);
     else LAUNCH_IG(IHM2MPC_MODEL_FKIN6);
