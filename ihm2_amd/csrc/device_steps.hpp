@@ -241,14 +241,15 @@ __device__ __forceinline__ void dev_linearize(
 // plant / rollout step: x_next = RK4 x M over dt; model -1 (-2: with fdyn6u) = kin/dyn switch of
 // python/main.py:482-489 (v^2 sin(beta) / l_R <= 3 -> kinematic, else dynamic).
 // The plain kinematic plant (model 0, the OCP's own model) is NOT handled here but by dev_sim_step_kin below.
-// one lane: instance b
-__device__ __forceinline__ void dev_sim_step(int b, int model, int M, double dt, int nknots,
+// FOUR lanes: instance b on the lanes q = 0..3 of a quad, all active -- every lane carries the state, the dynamic model's wheels are spread over
+// the lanes (fdyn6_eval_quad: bit-identical to the one-lane evaluation), lane q = 0 stores the result
+__device__ __forceinline__ void dev_sim_step(int b, int q, int model, int M, double dt, int nknots,
                                              const double *__restrict__ s_ref, const double *__restrict__ kappa_ref,
                                              const int32_t *__restrict__ track_id, const double *xs,
                                              const double *us, double *xn, const int32_t *active)
 {
     if (active && !active[b]) {          // a frozen instance keeps its state (closed loops: failed or finished cars)
-        if (xn != xs) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
+        if (xn != xs && q == 0) for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = xs[(size_t)b * 8 + i];
         return;
     }
     double x[8];
@@ -278,16 +279,17 @@ __device__ __forceinline__ void dev_sim_step(int b, int model, int M, double dt,
 #pragma unroll
             for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
             if (mdl == IHM2MPC_MODEL_FKIN6) fkin6_eval<false>(X, u_T, u_d, trk, K, J);
-            else if (mdl == IHM2MPC_MODEL_FDYN6U) fdyn6_eval<false, true>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval<false, false>(X, u_T, u_d, trk, K, J);
+            else if (mdl == IHM2MPC_MODEL_FDYN6U) fdyn6_eval_quad<true>(q, X, u_T, u_d, trk, K);
+            else fdyn6_eval_quad<false>(q, X, u_T, u_d, trk, K);
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) x[i] = xacc[i];
     }
+    if (q == 0)
 #pragma unroll
-    for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = x[i];
+        for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = x[i];
 }
 
 

@@ -197,9 +197,10 @@ __global__ __launch_bounds__(64) void k_sim_step(int B, int model, int M, double
                                                  const int32_t *__restrict__ track_id, const double *xs,
                                                  const double *__restrict__ us, double *xn, const int32_t *__restrict__ active)
 {
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    // four lanes per instance (the wheels of the dynamic model, device_steps.hpp): a quad is either whole inside the batch or whole outside
+    const int t = blockIdx.x * 64 + threadIdx.x, b = t >> 2;
     if (b >= B) return;
-    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active);
+    dev_sim_step(b, t & 3, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, active);
 }
 
 // the plain kinematic plant (model 0): the integrator of the shooting intervals on (x, u), see dev_sim_step_kin
@@ -247,7 +248,7 @@ void ihm2_launch_sim(ihm2mpc_handle *h, int model, int M_sim, const double *x, c
     if (model == IHM2MPC_MODEL_FKIN6 && (long)h->B * h->N > 128 && h->cfg.integrator_type == IHM2MPC_INTEG_ERK)
         hipLaunchKernelGGL(k_sim_step_kin, dim3(blocks), dim3(64), 0, stream, h->B, M_sim, h->cfg.dt, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id,
                            x, u, xn, active, h->lin + (size_t)h->B * h->N * LIN_REC);
-    else
-        hipLaunchKernelGGL(k_sim_step, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
+    else        // four lanes per instance
+        hipLaunchKernelGGL(k_sim_step, dim3((4 * h->B + 63) / 64), dim3(64), 0, stream, h->B, model, M_sim, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active);
 }

@@ -1138,10 +1138,11 @@ __device__ __noinline__ void call_linearize_irk(const IrkTab *tab, int b, int ba
     irk_linearize_quad<MODEL>(st, rows, x + ((size_t)b * (N + 1) + k) * 8, u + ((size_t)b * N + k) * 2, tid, nknots, s_ref, kappa_ref,
                               lin + ((size_t)b * N + k) * LIN_REC, q < N);
 }
-__device__ __noinline__ void call_sim_step(int b, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
+// (the lanes 0..3 of the wave: the dynamic plant's wheels are spread over a quad, device_steps.hpp)
+__device__ __noinline__ void call_sim_step(int b, int q, int model, int M, double dt, int nknots, const double *s_ref, const double *kappa_ref,
                                            const int32_t *track_id, const double *xs, const double *us, double *xn)
 {
-    dev_sim_step(b, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
+    dev_sim_step(b, q, model, M, dt, nknots, s_ref, kappa_ref, track_id, xs, us, xn, nullptr);
 }
 
 // the plant by collocation: every quad of the wave integrates the instance's control period (same arithmetic in all sixteen: the DPP
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
         double *spare = s.lin + (size_t)B * N * LIN_REC;
         if (!kin_plant && act) {
             if (irk_plant) call_sim_irk(s.sim_irk_tab, b, s.model, s.M_sim, s.nknots, s.s_ref, s.kappa_ref, a.track_id, a.u0, s.x0);
-            else if (lane == 0) call_sim_step(b, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
+            else if (lane < 4) call_sim_step(b, lane, s.model, s.M_sim, s.dt, s.nknots, s.s_ref, s.kappa_ref, a.track_id, s.x0, a.u0, s.x0);
             __syncthreads();
         }
         dev_prepare(b, lane, N, s.s_target, 2, s.x0, a.x, a.u, s.yref, s.yref_e);      // warm-start shift

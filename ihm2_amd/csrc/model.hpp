@@ -481,6 +481,86 @@ __device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r,
     sd_assign(rd, Mz * (1.0 / k_Iz));
 }
 
+// ---- the plant's force model on FOUR LANES: one wheel per lane ----
+// A plant step is one car on one lane for 100 RK4 sub-steps (python/main.py:395-400: 100 steps per control period) -- a chain nothing else of the
+// car can overlap, and four fifths of an evaluation are the four wheels' slip angles and Pacejka curves (two calls per wheel, ~570 instructions).
+// The lanes q = 0..3 of a quad take one wheel each (FL, FR, RL, RR) and hand the coefficients round by DPP quad broadcasts; everything else every
+// lane computes alike.  The same functions on the same operands as fdyn6_forces over doubles: BIT-IDENTICAL results, 2.5 x fewer instructions on
+// the chain.  All four lanes of the quad must be active.
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool UNCROSSED>
+__device__ inline void fdyn6_forces_quad(const int q, const double v_x, const double v_y, const double r, const double Tq, const double delta,
+                                         double &vxd, double &vyd, double &rd)
+{
+    double sd, cd;
+    msincos(delta, sd, cd);
+    const double F_down = v_x * v_x * (0.5 * k_Cdown);
+    const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track;
+    const double base = F_down * 0.25 + k_static_weight;
+    const double hx = 0.5 * k_axle_track;
+    const double v_x_FL = v_x - r * hx, v_x_FR = v_x + r * hx;
+    const double v_y_F = v_y + r * k_lF;
+    const double v_lon_FL = cd * v_x_FL + sd * v_y_F, v_lon_FR = cd * v_x_FR + sd * v_y_F;
+    const double v_lat_FL = cd * v_y_F - sd * v_x_FL, v_lat_FR = cd * v_y_F - sd * v_x_FR;
+    const double v_lat_R = v_y - r * k_lR;
+    // this lane's wheel: slip angle, then the Pacejka coefficient on its own angle (fdyn6u) or on the opposite wheel's (as written, quirk Q3)
+    const double v_lat_q = (q == 0) ? v_lat_FL : (q == 1) ? v_lat_FR : v_lat_R;
+    const double v_lon_q = (q == 0) ? v_lon_FL : (q == 1) ? v_lon_FR : (q == 2) ? v_x_FL : v_x_FR;
+    const double a_q = slip_angle_t(v_lat_q, v_lon_q);
+    const double g_q = lat_pacejka_t(UNCROSSED ? a_q : quad_perm_f64<0x1B>(a_q));          // quad_perm [3,2,1,0]: wheel k reads wheel 3 - k
+    const double glat0 = quad_perm_f64<0x00>(g_q), glat1 = quad_perm_f64<0x55>(g_q), glat2 = quad_perm_f64<0xAA>(g_q), glat3 = quad_perm_f64<0xFF>(g_q);
+    const double F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
+    const double beta = matan((sd / cd) * k_rwd);
+    const double r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
+    const double dtau = (r_kin - r) * k_Ktv;
+    const double idenom = k_Cm0 / (F_down * (-0.25) - k_m * k_g);
+    const double gm = (Tq - dtau) * idenom, gp = (Tq + dtau) * idenom;
+    const double cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;
+    const double cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;
+    const double cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
+    const double cz2 = -(gm * hx) - glat2 * k_lR, cz3 = gp * hx - glat3 * k_lR;
+    const double sumx = cx0 + cx1 + gm + gp, sumy = cy0 + cy1 + glat2 + glat3;
+    const double X0 = F_drag - sumx * base, Y0 = -(sumy * base);
+    const double Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
+    const double Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
+    const double a11 = -Xx + k_m, a12 = -Xy, a21 = -Yx, a22 = -Yy + k_m;
+    const double det = a11 * a22 - a12 * a21;
+    const double a_x = (X0 * a22 - a12 * Y0) / det;
+    const double a_y = (a11 * Y0 - a21 * X0) / det;
+    const double lx = a_x * cx, ly = a_y * cy;
+    const double Fz0 = -(base - lx + ly), Fz1 = -(base - lx - ly), Fz2 = -(base + lx + ly), Fz3 = -(base + lx - ly);
+    const double Mz = cz0 * Fz0 + cz1 * Fz1 + cz2 * Fz2 + cz3 * Fz3;
+    vxd = a_x + v_y * r;
+    vyd = a_y - v_x * r;
+    rd = Mz * (1.0 / k_Iz);
+}
+// xdot of the dynamic plant on the four lanes of a quad (no Jacobian): fdyn6_eval<false, UNCROSSED> with the wheels spread over the lanes
+template <bool UNCROSSED>
+__device__ inline void fdyn6_eval_quad(const int q, const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8])
+{
+    const double n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
+    double dk;
+    const double kap = trk.kappa(x[0], dk);
+    double sp, cp;
+    fast_sincos(psi, &sp, &cp);
+    const double num = v_x * cp - v_y * sp;
+    const double inv_dn = 1.0 / (1.0 + kap * n);
+    const double s_dot = num * inv_dn;
+    f[0] = s_dot;
+    f[1] = v_x * sp + v_y * cp;
+    f[2] = r - kap * s_dot;
+    f[6] = (u_T - T) * (1.0 / k_tT);
+    f[7] = (u_delta - delta) * (1.0 / k_tdelta);
+    fdyn6_forces_quad<UNCROSSED>(q, v_x, v_y, r, T, delta, f[3], f[4], f[5]);
+}
+
 // xdot (and with WITH_JAC the structural non-zeros of its Jacobian, pattern JX_MASK[1] / JU_MASK[1])
 template <bool WITH_JAC, bool UNCROSSED>
 __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
