@@ -102,12 +102,12 @@ __device__ __forceinline__ constexpr bool jnz(int a, int c)
     return (c < 8) ? ((JX_MASK[MODEL ? 1 : 0][a] >> c) & 1u) != 0 : ((JU_MASK[MODEL ? 1 : 0][a] >> (c - 8)) & 1u) != 0;
 }
 
-template <int MODEL>
+template <int MODEL, bool ROW = false>
 __device__ __forceinline__ void eval_model(const double (&X)[8], double u_T, double u_d, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
 {
     // (structural zeros of J are never written and never read: jnz)
     if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, f, J);
-    else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, f, J);
+    else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U, ROW>(X, u_T, u_d, trk, f, J);
 }
 
 // One collocation step of size tab.h from x for the quad (st = this lane's stage).  K: this lane's stage value on return.
@@ -119,7 +119,8 @@ __device__ __forceinline__ void eval_model(const double (&X)[8], double u_T, dou
 
 // Newton iterations of one collocation step from x; K: this lane's stage value, J: the model Jacobian at the final stage point
 // (evaluated only WITH_J, for the sensitivities).
-template <int MODEL, bool WITH_J>
+// ROW: the plants' variant (every quad of a 16-lane row on the same car): the dynamic model's wheels spread over the row (model.hpp)
+template <int MODEL, bool WITH_J, bool ROW = false>
 __device__ __forceinline__ void irk_step(const int st, const IrkRows &tab, const double (&x)[8], double u_T, double u_d, TrackSeg &trk,
                                          double (&K)[8], double (&J)[8][10])
 {
@@ -139,7 +140,7 @@ __device__ __forceinline__ void irk_step(const int st, const IrkRows &tab, const
             for (int j = 0; j < 4; j++) acc = fma(h * Arow[j], quad_get(K[a], j), acc);
             X[a] = acc;
         }
-        eval_model<MODEL>(X, u_T, u_d, trk, f, J);
+        eval_model<MODEL, ROW>(X, u_T, u_d, trk, f, J);
         if (last) break;
         // ---- Newton step: (I - h A (x) J) d = -(K - f), group by group ----
         double d[8];      // this lane's part of the step
@@ -293,7 +294,8 @@ __device__ __forceinline__ void irk_linearize_quad(const int st, const IrkRows &
 // one quad: Phi(xp_k + al (x_k - xp_k), up_k + al (u_k - up_k)) of one interval -> out (8), the line search's trial point
 // Plant step of one instance by its quad (python/main.py:395-400,476-502): x <- IRK x M over M steps of the tableau's h; model -1 / -2: the
 // kinematic / dynamic switch of python/main.py:482-489 (crossed / un-crossed slip angles), decided once at the start of the control period.
-// Every lane of the quad ends with the new state.  Shared by k_sim_irk and the persistent loop (bit-identical plant steps).
+// Every lane of the quad ends with the new state.  Shared by k_sim_irk and the persistent loop (bit-identical plant steps).  The FOUR quads of a
+// 16-lane row must be on the same car and active together: the dynamic model spreads its wheels over them (irk_step<.., ROW>).
 __device__ __forceinline__ void irk_sim_quad(const int st, const IrkRows &rows, const int model, const int M, double (&x)[8], const double u_T, const double u_d,
                                              TrackSeg &trk)
 {
@@ -308,8 +310,8 @@ __device__ __forceinline__ void irk_sim_quad(const int st, const IrkRows &rows, 
         double K[8], J[8][10];
         // the model is the same for the four lanes of a quad; quads of a wave may differ (the branch re-converges per step)
         if (mdl == IHM2MPC_MODEL_FKIN6) irk_step<IHM2MPC_MODEL_FKIN6, false>(st, rows, x, u_T, u_d, trk, K, J);
-        else if (mdl == IHM2MPC_MODEL_FDYN6) irk_step<IHM2MPC_MODEL_FDYN6, false>(st, rows, x, u_T, u_d, trk, K, J);
-        else irk_step<IHM2MPC_MODEL_FDYN6U, false>(st, rows, x, u_T, u_d, trk, K, J);
+        else if (mdl == IHM2MPC_MODEL_FDYN6) irk_step<IHM2MPC_MODEL_FDYN6, false, true>(st, rows, x, u_T, u_d, trk, K, J);
+        else irk_step<IHM2MPC_MODEL_FDYN6U, false, true>(st, rows, x, u_T, u_d, trk, K, J);
 #pragma unroll
         for (int a = 0; a < 8; a++) x[a] += quad_sum(hb * K[a]);
     }

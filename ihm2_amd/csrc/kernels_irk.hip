@@ -39,12 +39,13 @@ __global__ __launch_bounds__(64) void k_linearize_irk(int B, int N, int M, IrkTa
     irk_linearize_quad<MODEL>(st, rows, xk, uk, track_id[b], nknots, s_ref, kappa_ref, lin + ((size_t)b * N + k) * LIN_REC, live);
 }
 
-// plant step: x_next = IRK x M over dt, four lanes per instance; model -1 / -2: the kin / dyn switch of python/main.py:482-489
+// plant step: x_next = IRK x M over dt, SIXTEEN lanes per instance -- four quads (lane & 3 = collocation stage) that share the wheels of the dynamic
+// model between them (irk_body.hpp: irk_sim_quad); model -1 / -2: the kin / dyn switch of python/main.py:482-489
 __global__ __launch_bounds__(64) void k_sim_irk(int B, int model, int M, IrkTab tab, int nknots, const double *__restrict__ s_ref,
                                                 const double *__restrict__ kappa_ref, const int32_t *__restrict__ track_id, const double *xs,
                                                 const double *us, double *xn, const int32_t *__restrict__ active)
 {
-    const int bq = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const int bq = blockIdx.x * 4 + (threadIdx.x >> 4);
     const int b = min(bq, B - 1), st = threadIdx.x & 3;
     double x[8];
 #pragma unroll
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(64) void k_sim_irk(int B, int model, int M, IrkTab 
     const bool frozen = active && !active[b];
     IRK_ROWS(rows, tab, st)
     if (!frozen) irk_sim_quad(st, rows, model, M, x, u_T, u_d, trk);
-    if (bq < B && st == 0)
+    if (bq < B && (threadIdx.x & 15) == 0)
 #pragma unroll
         for (int a = 0; a < 8; a++) xn[(size_t)b * 8 + a] = x[a];
 }
@@ -180,7 +181,7 @@ int ihm2_upload_sim_irk_tab(ihm2mpc_handle *h, int M_sim)
 
 void ihm2_launch_sim_irk(ihm2mpc_handle *h, int model, int M_sim, const double *x, const double *u, double *xn, hipStream_t stream, const int32_t *active)
 {
-    const int blocks = (h->B + 15) / 16;
+    const int blocks = (h->B + 3) / 4;
     const IrkTab tab = make_tab(h->cfg.sim_integrator_type, h->cfg.dt / M_sim);
     hipLaunchKernelGGL(k_sim_irk, dim3(blocks), dim3(64), 0, stream, h->B, model, M_sim, tab, h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, x, u, xn, active);
 }

@@ -481,6 +481,74 @@ __device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r,
     sd_assign(rd, Mz * (1.0 / k_Iz));
 }
 
+// ---- the force model WITH its Jacobian on a ROW of sixteen lanes: the collocation plants (python/main.py:395-400) ----
+// The collocation step has one lane per stage (a quad); the plant of ONE car leaves the other quads of a 16-lane row with nothing of their own to do,
+// so the four quads of a row take one wheel each (w = (lane >> 2) & 3: FL, FR, RL, RR) for the slip angle and the Pacejka curve -- with their partial
+// derivatives, five slots -- and fetch the other wheels' coefficients from the lanes of the same stage (ds_bpermute).  Rear-wheel quantities are widened
+// to the front wheels' derivative mask (exact zeros in the steering slot): same values, same Jacobian as fdyn6_forces over the sparse duals.
+template <unsigned M> __device__ __forceinline__ SD<M> sd_pick4(const int w, const SD<M> &a0, const SD<M> &a1, const SD<M> &a2, const SD<M> &a3)
+{
+    SD<M> r;
+    r.v = (w == 0) ? a0.v : (w == 1) ? a1.v : (w == 2) ? a2.v : a3.v;
+    _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = (w == 0) ? a0.d[i] : (w == 1) ? a1.d[i] : (w == 2) ? a2.d[i] : a3.d[i];
+    return r;
+}
+template <unsigned M> __device__ __forceinline__ SD<M> sd_row_get(const SD<M> &a, const int src_lane)
+{
+    SD<M> r;
+    r.v = __shfl(a.v, src_lane);
+    _Pragma("unroll") for (int i = 0; i < sd_pc(M); i++) r.d[i] = __shfl(a.d[i], src_lane);
+    return r;
+}
+template <bool UNCROSSED, typename TVX, typename TVY, typename TR, typename TT, typename TD, typename TO>
+__device__ inline void fdyn6_forces_row(const TVX &v_x, const TVY &v_y, const TR &r, const TT &Tq, const TD &delta, TO &vxd, TO &vyd, TO &rd)
+{
+    constexpr unsigned WM = 0x17u;      // v_x, v_y, r, delta: what a front wheel's slip angle depends on
+    const int lane = threadIdx.x & 63, w = (lane >> 2) & 3, base_lane = lane & ~12;
+    TD sd, cd;
+    msincos(delta, sd, cd);
+    const auto F_down = v_x * v_x * (0.5 * k_Cdown);
+    const double cx = 0.5 * k_m * k_zCG / k_wheelbase, cy = 0.5 * k_m * k_zCG / k_axle_track;
+    const auto base = F_down * 0.25 + k_static_weight;
+    const double hx = 0.5 * k_axle_track;
+    const auto v_x_FL = v_x - r * hx, v_x_FR = v_x + r * hx;
+    const auto v_y_F = v_y + r * k_lF;
+    const auto v_lon_FL = cd * v_x_FL + sd * v_y_F, v_lon_FR = cd * v_x_FR + sd * v_y_F;
+    const auto v_lat_FL = cd * v_y_F - sd * v_x_FL, v_lat_FR = cd * v_y_F - sd * v_x_FR;
+    const auto v_lat_R = v_y - r * k_lR;
+    const SD<WM> v_lat_w = sd_pick4(w, sd_widen<WM>(v_lat_FL), sd_widen<WM>(v_lat_FR), sd_widen<WM>(v_lat_R), sd_widen<WM>(v_lat_R));
+    const SD<WM> v_lon_w = sd_pick4(w, sd_widen<WM>(v_lon_FL), sd_widen<WM>(v_lon_FR), sd_widen<WM>(v_x_FL), sd_widen<WM>(v_x_FR));
+    const SD<WM> a_w = slip_angle_t(v_lat_w, v_lon_w);
+    // crossed slip angles (quirk Q3): wheel k takes the angle of wheel 3 - k
+    const SD<WM> a_in = UNCROSSED ? a_w : sd_row_get(a_w, base_lane | ((3 - w) << 2));
+    const SD<WM> g_w = lat_pacejka_t(a_in);
+    const SD<WM> glat0 = sd_row_get(g_w, base_lane), glat1 = sd_row_get(g_w, base_lane | 4), glat2 = sd_row_get(g_w, base_lane | 8), glat3 = sd_row_get(g_w, base_lane | 12);
+    const auto F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
+    const auto beta = matan((sd / cd) * k_rwd);
+    const auto r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
+    const auto dtau = (r_kin - r) * k_Ktv;
+    const auto idenom = k_Cm0 / (F_down * (-0.25) - k_m * k_g);
+    const auto gm = (Tq - dtau) * idenom, gp = (Tq + dtau) * idenom;
+    const auto cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;
+    const auto cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;
+    const auto cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
+    const auto cz2 = -(gm * hx) - glat2 * k_lR, cz3 = gp * hx - glat3 * k_lR;
+    const auto sumx = cx0 + cx1 + gm + gp, sumy = cy0 + cy1 + glat2 + glat3;
+    const auto X0 = F_drag - sumx * base, Y0 = -(sumy * base);
+    const auto Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
+    const auto Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
+    const auto a11 = -Xx + k_m, a12 = -Xy, a21 = -Yx, a22 = -Yy + k_m;
+    const auto det = a11 * a22 - a12 * a21;
+    const auto a_x = (X0 * a22 - a12 * Y0) / det;
+    const auto a_y = (a11 * Y0 - a21 * X0) / det;
+    const auto lx = a_x * cx, ly = a_y * cy;
+    const auto Fz0 = -(base - lx + ly), Fz1 = -(base - lx - ly), Fz2 = -(base + lx + ly), Fz3 = -(base + lx - ly);
+    const auto Mz = cz0 * Fz0 + cz1 * Fz1 + cz2 * Fz2 + cz3 * Fz3;
+    sd_assign(vxd, a_x + v_y * r);
+    sd_assign(vyd, a_y - v_x * r);
+    sd_assign(rd, Mz * (1.0 / k_Iz));
+}
+
 // ---- the plant's force model on FOUR LANES: one wheel per lane ----
 // A plant step is one car on one lane for 100 RK4 sub-steps (python/main.py:395-400: 100 steps per control period) -- a chain nothing else of the
 // car can overlap, and four fifths of an evaluation are the four wheels' slip angles and Pacejka curves (two calls per wheel, ~570 instructions).
@@ -562,7 +630,8 @@ __device__ inline void fdyn6_eval_quad(const int q, const double (&x)[8], double
 }
 
 // xdot (and with WITH_JAC the structural non-zeros of its Jacobian, pattern JX_MASK[1] / JU_MASK[1])
-template <bool WITH_JAC, bool UNCROSSED>
+// ROW (collocation plants only, all sixteen lanes of a row on the same car and active): the wheels spread over the row's quads (fdyn6_forces_row)
+template <bool WITH_JAC, bool UNCROSSED, bool ROW = false>
 __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
 {
     const double n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
@@ -580,7 +649,8 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
     f[7] = (u_delta - delta) * (1.0 / k_tdelta);
     if (WITH_JAC) {
         SD<0x1Fu> o0, o1, o2;
-        fdyn6_forces<UNCROSSED>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
+        if constexpr (ROW) fdyn6_forces_row<UNCROSSED>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
+        else fdyn6_forces<UNCROSSED>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
         f[3] = o0.v; f[4] = o1.v; f[5] = o2.v;
 #pragma unroll
         for (int c = 0; c < 5; c++) { J[3][3 + c] = o0.d[c]; J[4][3 + c] = o1.d[c]; J[5][3 + c] = o2.d[c]; }
