@@ -118,9 +118,13 @@ def rti_throughput(model, B, steps=20, warmup=5, tracks=(TRACK,), terminal_bound
         ocp.model.con_h_expr = "track"
         c = ocp.constraints
         c.lh = c.lh_e = np.array([-1e3, -1e3]); c.uh = c.uh_e = np.array([0.0, 0.0])
-        if track_rows == "soft":
-            c.idxsh, c.idxsh_e = np.arange(2), np.arange(2)
-            ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(2, 100.0)
+        nh = 2
+        if track_rows == "soft+a_lat":  # the kinematic set with its fifth row, |a_lat| <= 5 m/s^2 (:198-209, :52-53), at the stages only
+            ocp.model.con_h_expr, nh = "track+a_lat", 3
+            c.lh = np.array([-1e3, -1e3, -5.0]); c.uh = np.array([0.0, 0.0, 5.0])
+        if track_rows in ("soft", "soft+a_lat"):
+            c.idxsh, c.idxsh_e = np.arange(nh), np.arange(2)
+            ocp.cost.zl = ocp.cost.zu = ocp.cost.Zl = ocp.cost.Zu = np.full(nh, 100.0)
             ocp.cost.zl_e = ocp.cost.zu_e = ocp.cost.Zl_e = ocp.cost.Zu_e = np.full(2, 100.0)
         widths = np.array([[p.right_widths.min(), p.left_widths.min()] for p in plans])
     s_ref = np.stack([p.s_ref for p in plans]); k_ref = np.stack([p.kappa_ref for p in plans])

@@ -55,6 +55,9 @@ SYMBOLS = {
     "ihm2mpc_set_bounds": (C.c_int, [_H] + [c_double_p] * 8),
     "ihm2mpc_set_soft": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_set_path_constraints": (C.c_int, [_H, C.c_int32, C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
+    "ihm2mpc_set_alat_constraint": (C.c_int, [_H, C.c_int32, C.c_double, C.c_double, c_double_p, c_double_p]),
+    "ihm2mpc_set_alat_multipliers": (C.c_int, [_H, c_double_p, c_double_p]),
+    "ihm2mpc_get_alat_multipliers": (C.c_int, [_H, c_double_p, c_double_p]),
     "ihm2mpc_set_x0": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_x": (C.c_int, [_H, c_double_p]),
     "ihm2mpc_set_u": (C.c_int, [_H, c_double_p]),

@@ -112,6 +112,7 @@ class IHM2Controller(Controller):
         soft_state_bounds: tuple | None = None,
         track_widths=None,
         track_rows_penalty: tuple | None = (100.0, 100.0),
+        lateral_acceleration_row: bool = False,
         recover_failed: bool = False,
     ) -> None:
         self.recover_failed = recover_failed
@@ -161,6 +162,17 @@ class IHM2Controller(Controller):
                 for name in ("Zl", "Zu"):
                     setattr(ocp.cost, name, np.concatenate([getattr(ocp.cost, name), np.full(2, Z_pen)]))
                     setattr(ocp.cost, name + "_e", np.concatenate([getattr(ocp.cost, name + "_e"), np.full(2, Z_pen)]))
+            if lateral_acceleration_row:
+                # the kinematic set's fifth row, |a_lat| <= ModelBounds.a_lat_max (old/generate_acaods_interface.py:198-209,
+                # :424, :433), at the stages only; softened like the track rows (idxsh = all, :436)
+                model.con_h_expr = "track+a_lat"
+                c.lh = np.concatenate([c.lh, [-a_lat_max]]); c.uh = np.concatenate([c.uh, [a_lat_max]])
+                if track_rows_penalty is not None:
+                    c.idxsh = np.arange(3)
+                    for name, v in (("zl", z_pen), ("zu", z_pen), ("Zl", Z_pen), ("Zu", Z_pen)):
+                        setattr(ocp.cost, name, np.concatenate([getattr(ocp.cost, name), [v]]))
+        elif lateral_acceleration_row:
+            raise ValueError("lateral_acceleration_row comes with the track rows (track_widths): old/generate_acaods_interface.py:198-209")
         opts = AcadosOcpOptions()                      # python/main.py:227-238, with ERK x M for IRK
         opts.tf = Nf * dt
         opts.nlp_solver_type = nlp_solver_type

@@ -90,6 +90,13 @@ int ready(ihm2mpc_handle *h)
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (!h->weights_set) return fail("ihm2mpc_set_weights has not been called");
     if (!h->bounds_set) return fail("ihm2mpc_set_bounds has not been called");
+    if (h->alat_on) {
+        // the row belongs to the kinematic constraint set of old/generate_acaods_interface.py:198-209, which comes with the track rows and SQP_RTI (old/generate.py:21)
+        if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return fail("the lateral-acceleration row is a row of the kinematic model (old/generate_acaods_interface.py:206: `[] if is_dynamic else [a_lat]`)");
+        if (!h->path_on) return fail("the lateral-acceleration row comes with the track rows: enable ihm2mpc_set_path_constraints first");
+        if (h->cfg.nlp_solver_type != IHM2MPC_SQP_RTI) return fail("the lateral-acceleration row is implemented for SQP_RTI (old/generate.py:21)");
+        if (!(h->uniform_H && h->uniform_CD)) return fail("the lateral-acceleration row needs stage-independent weights and general rows (the reference's OCP has them)");
+    }
     return 0;
 }
 
@@ -167,7 +174,8 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(CD, N * 20); DA(lg, N * 2); DA(ug, N * 2);
     DA(slot_kc_blk, 1024); DA(slot_lb_blk, 1024); DA(slot_ub_blk, 1024);
     DA(slot_kc, MAX_SLOTS); DA(slot_lb, MAX_SLOTS); DA(slot_ub, MAX_SLOTS); DA(slot_zw, MAX_SLOTS); DA(slot_Zw, MAX_SLOTS);
-    DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2);
+    DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2); DA(lam_a, B * NS * 2); DA(slk_a, B * NS * 2);
+    h->alat_on = 0; h->alat_lb = -INFINITY; h->alat_ub = INFINITY; h->alat_sz[0] = h->alat_sz[1] = 0.0; h->alat_sZ[0] = h->alat_sZ[1] = -1.0;
     DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
     DA(xc, B * 8); DA(s_guess, B);
     DA(step_args, 32);
@@ -200,7 +208,7 @@ int ihm2mpc_free(ihm2mpc_handle *h)
     (void)hipStreamSynchronize(h->stream);
     (void)ihm2mpc_comm_free(h);
     void *ptrs[] = {h->s_ref, h->kappa_ref, h->track_id, h->Hs, h->Gy, h->lbx, h->ubx, h->lbu, h->ubu, h->CD, h->lg, h->ug,
-                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
+                    h->slot_kc, h->slot_lb, h->slot_ub, h->slot_zw, h->slot_Zw, h->slk, h->lam_a, h->slk_a, h->widths, h->X_ref, h->Y_ref, h->phi_ref, h->xc, h->s_guess, h->x, h->u, h->x0, h->yref, h->yref_e, h->pi, h->lam, h->res, h->qp_res, h->dyn10, h->ls_phi, h->slot_kc_blk, h->slot_lb_blk, h->slot_ub_blk,
                     h->status, h->qp_iter, h->active, h->u0, h->lin, h->q_g, h->q_rg, h->q_P, h->q_M, h->scratch, h->step_args, h->Wd, h->st_lb, h->st_ub, h->st_sz, h->st_sZ,
                     h->ls_x, h->ls_u, h->ls_pi, h->ls_lam, h->ls_slk, h->ls_wpi, h->ls_wlam, h->ls_alpha, h->ls_args, h->ls_done, h->ls_status, h->ls_iter, h->ls_qp_acc, h->ls_pending, h->irk_tab, h->sim_irk_tab,
                     h->hist_u0, h->hist_x0, h->hist_st, h->hist_it};
@@ -398,13 +406,18 @@ static int rebuild_slots(ihm2mpc_handle *h)
     int nsoft[64] = {0};
     int m_act = 0, total = 0;
     // two passes: rows with a soft side first, spread by soft count, then the hard rows by total count
+    // (row 14: the lateral-acceleration row of the stages 1..N-1, kept beside the NC = 14 rows of the tables)
     for (int pass = 0; pass < 2; pass++)
         for (int k = 0; k < NS; k++)
-            for (int c = 0; c < NC; c++) {
-                const double lb = h->host_lb[k * NC + c], ub = h->host_ub[k * NC + c];
+            for (int c = 0; c < NC + 1; c++) {
+                const bool extra = c == NC;
+                if (extra && !(h->alat_on && k >= 1 && k < NS - 1)) continue;
+                const double lb = extra ? h->alat_lb : h->host_lb[k * NC + c], ub = extra ? h->alat_ub : h->host_ub[k * NC + c];
                 const bool fl = std::isfinite(lb), fu = std::isfinite(ub);
                 if (!fl && !fu) continue;
-                const bool sl = fl && h->host_sZ[k * NLAM + c] >= 0.0, su = fu && h->host_sZ[k * NLAM + NC + c] >= 0.0;
+                const double szl = extra ? h->alat_sz[0] : h->host_sz[k * NLAM + c], sZl = extra ? h->alat_sZ[0] : h->host_sZ[k * NLAM + c];
+                const double szu = extra ? h->alat_sz[1] : h->host_sz[k * NLAM + NC + c], sZu = extra ? h->alat_sZ[1] : h->host_sZ[k * NLAM + NC + c];
+                const bool sl = fl && sZl >= 0.0, su = fu && sZu >= 0.0;
                 if ((sl || su) != (pass == 0)) continue;
                 int best = 0;       // least-loaded lane; ties -> lowest lane (round-robin for an all-hard table)
                 for (int l = 1; l < 64; l++) {
@@ -415,8 +428,8 @@ static int rebuild_slots(ihm2mpc_handle *h)
                 std::vector<Slot> &L = lanes[best];
                 if (!sl && !su) L.push_back({k * 16 + c, lb, ub, 0.0, -1.0});
                 else {
-                    if (fl) L.push_back({k * 16 + c, lb, INFINITY, sl ? h->host_sz[k * NLAM + c] : 0.0, sl ? h->host_sZ[k * NLAM + c] : -1.0});
-                    if (fu) L.push_back({k * 16 + c, -INFINITY, ub, su ? h->host_sz[k * NLAM + NC + c] : 0.0, su ? h->host_sZ[k * NLAM + NC + c] : -1.0});
+                    if (fl) L.push_back({k * 16 + c, lb, INFINITY, sl ? szl : 0.0, sl ? sZl : -1.0});
+                    if (fu) L.push_back({k * 16 + c, -INFINITY, ub, su ? szu : 0.0, su ? sZu : -1.0});
                 }
                 nsoft[best] += (int)sl + (int)su;
                 m_act += (int)fl + (int)fu + (int)sl + (int)su;
@@ -545,6 +558,47 @@ int ihm2mpc_set_path_constraints(ihm2mpc_handle *h, int32_t enable, double car_l
     return 0;
 }
 
+int ihm2mpc_set_alat_constraint(ihm2mpc_handle *h, int32_t enable, double a_lat_min, double a_lat_max, const double *soft_z, const double *soft_Z)
+{
+    CHECK_H(h);
+    if (enable) {
+        if (a_lat_min != a_lat_min || a_lat_max != a_lat_max) return fail("a_lat bound is not a number");
+        if (a_lat_min > a_lat_max) return fail("a_lat_min > a_lat_max");
+        for (int i = 0; i < 2; i++) {
+            const double z = soft_z ? soft_z[i] : 0.0, Z = soft_Z ? soft_Z[i] : -1.0;
+            if (z != z || Z != Z) return fail("soft penalty of the a_lat row is not a number");
+            if (Z >= 0.0 && !(z >= 0.0)) return fail("soft_z < 0 on the a_lat row (the slack penalty must be non-decreasing)");
+            if (Z >= 0.0 && !(Z + z > 0.0)) return fail("a soft side of the a_lat row has neither a linear nor a quadratic penalty");
+            h->alat_sz[i] = z; h->alat_sZ[i] = Z;
+        }
+        h->alat_lb = (std::fabs(a_lat_min) < 1e20) ? a_lat_min : -INFINITY;
+        h->alat_ub = (std::fabs(a_lat_max) < 1e20) ? a_lat_max : INFINITY;
+    }
+    h->alat_on = enable ? 1 : 0;
+    HIP_TRY(hipMemsetAsync(h->lam_a, 0, (size_t)h->B * h->NS * 2 * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->slk_a, 0, (size_t)h->B * h->NS * 2 * sizeof(double), h->stream));
+    if (h->bounds_set && rebuild_slots(h)) return -1;
+    return 0;
+}
+
+int ihm2mpc_set_alat_multipliers(ihm2mpc_handle *h, const double *lam, const double *slk)
+{
+    CHECK_H(h);
+    if (lam) { if (upload(h, lam, h->lam_a, h->NS * 2)) return -1; }
+    else HIP_TRY(hipMemsetAsync(h->lam_a, 0, (size_t)h->B * h->NS * 2 * sizeof(double), h->stream));
+    if (slk) { if (upload(h, slk, h->slk_a, h->NS * 2)) return -1; }
+    else HIP_TRY(hipMemsetAsync(h->slk_a, 0, (size_t)h->B * h->NS * 2 * sizeof(double), h->stream));
+    return 0;
+}
+
+int ihm2mpc_get_alat_multipliers(ihm2mpc_handle *h, double *lam, double *slk)
+{
+    CHECK_H(h);
+    if (lam && download(h, h->lam_a, lam, h->NS * 2)) return -1;
+    if (slk && download(h, h->slk_a, slk, h->NS * 2)) return -1;
+    return 0;
+}
+
 #define SETTER(name, field, elems)                                   \
     int ihm2mpc_set_##name(ihm2mpc_handle *h, const double *v)       \
     {                                                                \
@@ -565,7 +619,10 @@ int ihm2mpc_set_multipliers(ihm2mpc_handle *h, const double *pi, const double *l
     if (pi) { if (upload(h, pi, h->pi, h->NS * NX)) return -1; }
     else HIP_TRY(hipMemsetAsync(h->pi, 0, (size_t)h->B * h->NS * NX * sizeof(double), h->stream));
     if (lam) { if (upload(h, lam, h->lam, h->NS * NLAM)) return -1; }
-    else HIP_TRY(hipMemsetAsync(h->lam, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
+    else {
+        HIP_TRY(hipMemsetAsync(h->lam, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
+        HIP_TRY(hipMemsetAsync(h->lam_a, 0, (size_t)h->B * h->NS * 2 * sizeof(double), h->stream));      // "no multipliers" covers row 14 as well
+    }
     return 0;
 }
 
@@ -574,6 +631,7 @@ int ihm2mpc_set_slacks(ihm2mpc_handle *h, const double *sl)
     CHECK_H(h);
     if (sl) return upload(h, sl, h->slk, h->NS * NLAM);
     HIP_TRY(hipMemsetAsync(h->slk, 0, (size_t)h->B * h->NS * NLAM * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->slk_a, 0, (size_t)h->B * h->NS * 2 * sizeof(double), h->stream));
     return 0;
 }
 

@@ -66,6 +66,9 @@ struct ihm2mpc_handle {
     int path_on;
     double car_L, car_W, lh[NH], uh[NH];
     double *widths;                // (ntracks, 2) = (w_R, w_L), device
+    // lateral-acceleration row of the kinematic constraint set (row 14 of the stages 1..N-1; ihm2mpc_set_alat_constraint)
+    int alat_on;
+    double alat_lb, alat_ub, alat_sz[2], alat_sZ[2];      // bounds (+-inf = absent), slack penalties of the lower / upper side (sZ < 0 = hard)
     // Cartesian side (ROS stack): centre-line geometry per track, Cartesian plant state and projection guess per instance
     bool geometry_set;
     double *X_ref, *Y_ref, *phi_ref;   // (ntracks, nknots)
@@ -81,6 +84,7 @@ struct ihm2mpc_handle {
     double *pi;     // (B,NS,8)
     double *lam;    // (B,NS,28)
     double *slk;    // (B,NS,28) slack values of the soft sides after the last QP (0 for hard sides)
+    double *lam_a, *slk_a;   // (B,NS,2) multipliers and slack values of the lateral-acceleration row: lower, upper side
     double *res;    // (B,4)
     double *ls_phi; // (n_alpha, B, N, 8) IRK rollouts at the trial points of the line search (SQP mode with the IRK integrator)
     int ls_nalpha;

@@ -63,6 +63,8 @@ struct QpArgs {
     const int32_t *track_id;
     const double *widths;
     double car_L, car_W;
+    // lateral-acceleration row (PATH == 2): its multipliers and slack values, (B, N+1, 2) = lower, upper side -- beside the 28 columns of the other rows
+    double *lam_a, *slk_a;
     int symmetrize;     // P_k := (P_k + P_k') / 2 in the factor sweep (riccati_mfma.hpp): needed by the open-loop unstable dynamic model as written (fdyn6)
 };
 
@@ -251,9 +253,10 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #define BSYNC() do { if (NW == 1) WSYNC(); else __syncthreads(); } while (0)
     const int N = a.N, NS = N + 1;
-    // constraint rows per stage held in LDS: 8 x boxes, 2 u boxes, 2 general rows (+ 2 track rows); the multiplier arrays in
-    // HBM always have the full NLAM = 28 columns (14 lower sides, then 14 upper sides)
-    constexpr int NCK = PATH ? 14 : 12;
+    // constraint rows per stage held in LDS: 8 x boxes, 2 u boxes, 2 general rows (+ 2 track rows (+ the lateral-acceleration row, PATH == 2)); the
+    // multiplier arrays in HBM always have the full NLAM = 28 columns (14 lower sides, then 14 upper sides); row 14 keeps its two in lam_a / slk_a
+    constexpr int NCK = (PATH == 2) ? 15 : PATH ? 14 : 12;
+    constexpr bool ALAT = PATH == 2;
     // UNI: the stage Hessians H_0..H_{N-1} and the general rows [C D]_k do not depend on k (the reference's OCP: one W, one C, D
     // for all stages, python/mpc.py:49-99).  They are then kept in LDS (H only where the budget of 40 KB per instance allows)
     // instead of being fetched through L2 with lane-dependent addresses in every phase.
@@ -273,7 +276,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *Prb = Ginv + N * 8;      // N*8    P_{k+1} rb_k (same for predictor and corrector)
     double *tile = Prb + N * 8;      // 8*17   transpose tile of the factor sweep
     double *hc = tile + 136;         // NS*2   d h_R / d psi, d h_L / d psi of the track rows (PATH only)
-    double *Hl = hc + (PATH ? NS * 2 : 0);   // 200  stage and terminal Hessian (HL only)
+    double *ha = hc + (PATH ? NS * 2 : 0);   // NS*4   d a_lat / d (v_x, v_y, T, delta) of the lateral-acceleration row (PATH == 2; zeros where the row is absent)
+    double *Hl = ha + (ALAT ? NS * 4 : 0);   // 200  stage and terminal Hessian (HL only)
     double *CDl = Hl + (HL ? 200 : 0);       // 20   general rows (CL only)
     double *spv = CDl + (CL ? 20 : 0);       // 60   the (up to three) non-zeros of every row of the two Hessians (HL only) ...
     int *spc = reinterpret_cast<int *>(spv + 60);      // 60 ints: ... and their columns
@@ -309,6 +313,10 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *pib = a.pi + (size_t)b * NS * 8;
     double *lamb = a.lam + (size_t)b * NS * 28;
     double *slkb = a.slk + (size_t)b * NS * 28;
+    double *lamab = ALAT ? a.lam_a + (size_t)b * NS * 2 : nullptr;
+    double *slkab = ALAT ? a.slk_a + (size_t)b * NS * 2 : nullptr;
+    // column of the state a non-zero of the lateral-acceleration row sits in (v_x, v_y, T, delta), and back
+    auto alat_slot = [](int j) -> int { return (j == 3) ? 0 : (j == 4) ? 1 : (j == 6) ? 2 : (j == 7) ? 3 : -1; };
 
     // ------------------------------------------------------------------ QP data + NLP residuals
     // gradient g_k = H_k z_k - Gy_k yref_k, and the stationarity of the NLP with the incoming multipliers
@@ -346,6 +354,13 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             const double dfoot = -0.5 * a.car_L * cos(fabs(psi)) * sgn, dlat = -0.5 * a.car_W * sin(psi);
             hc[k * 2 + 0] = (k >= 1) ? dfoot + dlat : 0.0;
             hc[k * 2 + 1] = (k >= 1) ? -dfoot + dlat : 0.0;
+            if (ALAT) {
+                // the lateral-acceleration row lives on the stages 1..N-1 (it is no terminal row: con_h_expr_e, old/generate_acaods_interface.py:209-212)
+                double g4[4];
+                alat_eval(xb[k * 8 + 3], xb[k * 8 + 4], xb[k * 8 + 6], xb[k * 8 + 7], g4);
+#pragma unroll
+                for (int q = 0; q < 4; q++) ha[k * 4 + q] = (k >= 1 && k < N) ? g4[q] : 0.0;
+            }
         }
         BSYNC();
     }
@@ -386,6 +401,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             const double l12 = lamb[k * 28 + 12] - lamb[k * 28 + 26], l13 = lamb[k * 28 + 13] - lamb[k * 28 + 27];
             st -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
         }
+        if (ALAT && alat_slot(j) >= 0) st -= ha[k * 4 + alat_slot(j)] * (lamab[k * 2] - lamab[k * 2 + 1]);
         if (counted) r_stat = fmax(r_stat, fabs(st));
     }
     for (int e = tid; e < N * 8; e += NT) {
@@ -426,7 +442,10 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             double cz;
             if (c < 8) cz = xb[k * 8 + c];
             else if (c < 10) cz = ub[k * 2 + c - 8];
-            else if (c >= 12) {
+            else if (ALAT && c == 14) {
+                double g4[4];
+                cz = alat_eval(xb[k * 8 + 3], xb[k * 8 + 4], xb[k * 8 + 6], xb[k * 8 + 7], g4);
+            } else if (c >= 12) {
                 const double n = xb[k * 8 + 1], psi = xb[k * 8 + 2];
                 const double foot = -0.5 * a.car_L * sin(fabs(psi)), lat = 0.5 * a.car_W * cos(psi);
                 cz = (c == 12) ? n + foot + lat - w_R : -n - foot + lat - w_L;
@@ -441,8 +460,9 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             bool soft = false;
             if (r < NSOFT) { so_zw[r < NSOFT ? r : 0] = a.slot_zw[s]; so_Zw[r < NSOFT ? r : 0] = a.slot_Zw[s]; soft = a.slot_Zw[s] >= 0.0; }
             // soft sides may be violated: they do not count as infeasibility of the iterate
-            if (fin(lb)) { s_dl[r] = lb - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + c] * s_dl[r])); } }
-            if (fin(ubd)) { s_du[r] = ubd - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lamb[k * 28 + 14 + c] * s_du[r])); } }
+            const double lam_in_l = (ALAT && c == 14) ? lamab[k * 2] : lamb[k * 28 + c], lam_in_u = (ALAT && c == 14) ? lamab[k * 2 + 1] : lamb[k * 28 + 14 + c];
+            if (fin(lb)) { s_dl[r] = lb - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lam_in_l * s_dl[r])); } }
+            if (fin(ubd)) { s_du[r] = ubd - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lam_in_u * s_du[r])); } }
         }
     }
     if (want_res) { r_stat = blk_max(r_stat); r_eq = blk_max(r_eq); r_ineq = blk_max(r_ineq); r_comp = blk_max(r_comp); }
@@ -460,6 +480,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     auto row_dot = [&](int kc, const double *v) -> double {
         const int k = kc / NCK, c = kc % NCK;
         if (c < 10) return v[k * 10 + c];
+        if (ALAT && c == 14) return ha[k * 4] * v[k * 10 + 3] + ha[k * 4 + 1] * v[k * 10 + 4] + ha[k * 4 + 2] * v[k * 10 + 6] + ha[k * 4 + 3] * v[k * 10 + 7];
         if (PATH && c >= 12) return (c == 12) ? v[k * 10 + 1] + hc[k * 2] * v[k * 10 + 2] : -v[k * 10 + 1] + hc[k * 2 + 1] * v[k * 10 + 2];
         double acc = 0.0;
 #pragma unroll
@@ -592,6 +613,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                         const double l12 = cf[k * NCK + 12], l13 = cf[k * NCK + 13];
                         acc -= (j == 1) ? l12 - l13 : hc[k * 2] * l12 + hc[k * 2 + 1] * l13;
                     }
+                    if (ALAT && alat_slot(j) >= 0) acc -= ha[k * 4 + alat_slot(j)] * cf[k * NCK + 14];
                     gt[e] = acc;
                 }
                 BSYNC();
@@ -686,6 +708,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     const double c12 = cf[k * NCK + 12], c13 = cf[k * NCK + 13];
                     acc += (j == 1) ? c12 - c13 : hc[k * 2] * c12 + hc[k * 2 + 1] * c13;
                 }
+                if (ALAT && alat_slot(j) >= 0) acc += ha[k * 4 + alat_slot(j)] * cf[k * NCK + 14];
                 gt[e] = acc;        // pass 1 adds its increment on top of the predictor's gradient
             }
             BSYNC();
@@ -702,8 +725,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             // build both flat addresses -- and mis-fold their null checks in the register-starved instantiations)
             RicLds L;
             L.gt = NS * 10; L.pv = NS * 28; L.gam = NS * 36 + N * 8; L.dz = L.gam + 2 * NS * NCK; L.kff = L.dz + NS * 10; L.Kl = L.kff + N * 4;
-            L.Ginv = L.Kl + N * 16; L.hv = L.Ginv + N * 8; L.tile = L.hv + N * 8; L.hc = L.tile + 136;
-            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, RIC_RING>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0, a.symmetrize != 0);
+            L.Ginv = L.Kl + N * 16; L.hv = L.Ginv + N * 8; L.tile = L.hv + N * 8; L.hc = L.tile + 136; L.ha = L.hc + NS * 2;
+            riccati_sweep_mfma<NCK, PATH != 0, UNI != 0, RIC_RING, ALAT>(N, lane, linb, a.Hs, a.CD, L, Pg, Mg, LIN_REC, a.m_act == 0, a.symmetrize != 0);
             if (lane < 8) dz[lane] = 0.0;
         }
         BSYNC();
@@ -1054,6 +1077,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
     double *xw = a.x + (size_t)b * NS * 8, *uw = a.u + (size_t)b * N * 2;
     if (NSOFT > 0) {        // slacks of a failed instance read 0; an all-hard table never touches the array
         for (int e = tid; e < NS * 28; e += NT) slkb[e] = 0.0;
+        if (ALAT) for (int e = tid; e < NS * 2; e += NT) slkab[e] = 0.0;
     }
     if (st == 0) {
         for (int e = tid; e < NS * 10; e += NT) {
@@ -1063,11 +1087,18 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         }
         for (int e = tid; e < NS * 8; e += NT) pib[e] = (e < 8) ? 0.0 : pi[e];
         for (int e = tid; e < NS * 28; e += NT) lamb[e] = 0.0;
+        if (ALAT) for (int e = tid; e < NS * 2; e += NT) lamab[e] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
             const int k = s_kc[r] / NCK, c = s_kc[r] % NCK;
+            if (ALAT && c == 14) {
+                if (fin(s_dl[r])) lamab[k * 2] = lam_l[r];
+                if (fin(s_du[r])) lamab[k * 2 + 1] = lam_u[r];
+                if (IS_SOFT(r)) slkab[k * 2 + (fin(s_dl[r]) ? 0 : 1)] = so_s[r < NSOFT ? r : 0];
+                continue;
+            }
             if (fin(s_dl[r])) lamb[k * 28 + c] = lam_l[r];
             if (fin(s_du[r])) lamb[k * 28 + 14 + c] = lam_u[r];
             if (IS_SOFT(r)) slkb[k * 28 + (fin(s_dl[r]) ? c : 14 + c)] = so_s[r < NSOFT ? r : 0];
@@ -1333,9 +1364,9 @@ __global__ __launch_bounds__(64) void k_steps(const StepArgs *sp, QpArgs a, cons
 static size_t qp_lds_bytes(const ihm2mpc_handle *h)
 {
     const size_t N = h->N, NS = h->NS;
-    const int nck = h->path_on ? 14 : 12;
+    const int nck = h->path_on ? (h->alat_on ? 15 : 14) : 12;
     const int uni = h->uniform_H && h->uniform_CD;
-    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? 2 : 0)) + N * (8 + 4 + 16 + 8 + 8) + 136 + (uni ? 20 + (h->path_on ? 0 : 200 + 90) : 0));
+    return sizeof(double) * (NS * (10 + 10 + 8 + 8 + 2 * nck + 10 + (h->path_on ? (h->alat_on ? 6 : 2) : 0)) + N * (8 + 4 + 16 + 8 + 8) + 136 + (uni ? 20 + (h->path_on ? 0 : 200 + 90) : 0));
 }
 
 static QpArgs qp_args(ihm2mpc_handle *h)
@@ -1350,6 +1381,7 @@ static QpArgs qp_args(ihm2mpc_handle *h)
     a.lin = h->lin; a.g = h->q_g; a.rg = h->q_rg; a.P = h->q_P; a.M = h->q_M + (size_t)QM_PAD * 64;
     a.slot_zw = h->slot_zw; a.slot_Zw = h->slot_Zw; a.slk = h->slk;
     a.track_id = h->track_id; a.widths = h->widths; a.car_L = h->car_L; a.car_W = h->car_W;
+    a.lam_a = h->lam_a; a.slk_a = h->slk_a;
     a.symmetrize = (h->cfg.model == IHM2MPC_MODEL_FDYN6) ? 1 : 0;
     return a;
 }
@@ -1372,6 +1404,7 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
                           double *hist_u0, double *hist_x0, int32_t *hist_st, int32_t *hist_it)
 #endif
 {
+    if (h->alat_on) return 1;       // the lateral-acceleration row has no instantiation of the persistent loop: launches per step (same results)
     const bool dyn = h->cfg.model != IHM2MPC_MODEL_FKIN6;
 #if QP_SET == 0
     if (dyn) return ihm2_launch_steps_dyn(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
@@ -1519,7 +1552,12 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0, 0);
     else return 2;
 #else
-    if (!h->path_on) {
+    if (h->alat_on) {
+        // track rows + the lateral-acceleration row (ready() has checked: kinematic model, track rows on, batch-shared tables)
+        if (!uni || !h->path_on || nsoft > 4 || per_lane > 10) return 2;
+        (void)hipFuncSetAttribute((const void *)k_qp_wave<10, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_qp_wave<10, 4, 2, 1>), dim3(h->B), dim3(64), lds, h->stream, a);
+    } else if (!h->path_on) {
         if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 0);
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 0);
         else return 2;

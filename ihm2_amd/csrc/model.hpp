@@ -209,6 +209,32 @@ __device__ __forceinline__ void fkin6_eval(const double (&x)[8], double u_T, dou
     }
 }
 
+// ---- lateral acceleration of the kinematic model: the fifth nonlinear row of the kinematic constraint set ----
+// old/generate_acaods_interface.py:198-209 (`+ ([] if is_dynamic else [a_lat])`), definition :266-271 and old/scripts/gen_mpc.py:182-184:
+//   a_lat = (-F_Rx sin(beta) + F_Fx sin(delta - beta)) / m + (v_x^2 + v_y^2) sin(beta) / l_R
+// with the forces and the slip angle of fkin6 (python/models.py:255-263).  g = d a_lat / d (v_x, v_y, T, delta): the row's non-zeros.
+__device__ __forceinline__ double alat_eval(const double v_x, const double v_y, const double T, const double delta, double (&g)[4])
+{
+    const double c = k_rwd;
+    const double sg = tanh_e(10.0 * v_x);
+    const double poly = k_Cr0 + k_Cr1 * v_x + k_Cr2 * v_x * v_x;
+    const double F_Rx = 0.5 * k_Cm0 * T - poly * sg, F_Fx = 0.5 * k_Cm0 * T;
+    double sd, cd;
+    fast_sincos(delta, &sd, &cd);
+    const double td = sd / cd;
+    const double hyp = 1.0 / sqrt(cd * cd + c * c * sd * sd);
+    const double cb = cd * hyp, sb = c * sd * hyp;
+    const double bp = c * (1.0 + td * td) / (1.0 + c * c * td * td);      // d beta / d delta
+    const double cdb = cd * cb + sd * sb, sdb = sd * cb - cd * sb;          // cos / sin (delta - beta)
+    const double vv = v_x * v_x + v_y * v_y;
+    const double dFdrag = -(k_Cr1 + 2.0 * k_Cr2 * v_x) * sg - poly * 10.0 * (1.0 - sg * sg);
+    g[0] = -dFdrag * sb * (1.0 / k_m) + 2.0 * v_x * sb * (1.0 / k_lR);
+    g[1] = 2.0 * v_y * sb * (1.0 / k_lR);
+    g[2] = 0.5 * k_Cm0 * (sdb - sb) * (1.0 / k_m);
+    g[3] = (-F_Rx * cb * bp + F_Fx * cdb * (1.0 - bp)) * (1.0 / k_m) + vv * cb * bp * (1.0 / k_lR);
+    return (-F_Rx * sb + F_Fx * sdb) * (1.0 / k_m) + vv * sb * (1.0 / k_lR);
+}
+
 // Structural pattern of d f_i / d x_l (bit l of JX_MASK[model][i]) and of d f_i / d u (bit 0: u_T, bit 1: u_delta).
 // fdyn6: rows 3..5 (v_x_dot, v_y_dot, r_dot) depend on (v_x, v_y, r, T, delta) and on no input directly.
 __device__ constexpr unsigned JX_MASK[2][8] = {{0x1Fu, 0x1Cu, 0x3Fu, 0xD8u, 0xC8u, 0xC8u, 0x40u, 0x80u},

@@ -77,6 +77,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 struct RicLds {
     int gam;      // (NS,NCK) barrier weights per constraint row
     int hc;       // (NS,2)   track-row slopes (PATH)
+    int ha;       // (NS,4)   non-zeros of the lateral-acceleration row in (v_x, v_y, T, delta) (ALAT; zeros where the row is absent)
     int gt;       // (NS,10)  in: modified gradient of the predictor
     int pv;       // (NS,8)   out: p_N, and p_k (k < N) if store_p
     int hv;       // (N,8)    out: P_{k+1} rb_k
@@ -152,7 +153,8 @@ __device__ __forceinline__ void dyn_residual(const int N, const int lane, double
 // Backward sweep.  In (LDS): gam, hc, gt = the predictor's gradient incl. [A B]'pi; in the records: A, B and rb (slot 88).
 // Out: LDS arrays of RicLds; HBM: Pg (NS,64), Mg (N,64) in the RIC_IDX layout.  store_p (wave-uniform): also keep p_k, k < N.
 // Hs (NS,10,10), CD (N,2,10): batch-shared; UNI: the same for all k < N.  D: depth of the record prefetch ring.
-template <int NCK, bool PATH, bool UNI, int D>
+// ALAT: a fifteenth row per stage, gam[k][14] a a' with a = the four non-zeros in L.ha (stages 1..N-1).
+template <int NCK, bool PATH, bool UNI, int D, bool ALAT = false>
 __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, const double *__restrict__ linb, const double *__restrict__ Hs,
                                                    const double *__restrict__ CD, const RicLds L, double *__restrict__ Pg, double *__restrict__ Mg,
                                                    const int lin_rec, const bool store_p, const bool symmetrize)
@@ -193,6 +195,11 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
     // track rows (PATH): entries (n,n), (n,psi), (psi,psi) of H~ -- result register 0 of the lane groups 1, 2
     const double p11 = (PATH && row[0] == 1 && col == 1) ? 1.0 : 0.0, p22 = (PATH && row[0] == 2 && col == 2) ? 1.0 : 0.0;
     const double p12 = (PATH && ((row[0] == 1 && col == 2) || (row[0] == 2 && col == 1))) ? 1.0 : 0.0;
+    // lateral-acceleration row (ALAT): gam14 a_i a_l on the entries (i, l) of {v_x, v_y, T, delta}^2 -- state rows sit in the result registers 0, 1
+    auto a_slot = [](int c) -> int { return (c == 3) ? 0 : (c == 4) ? 1 : (c == 6) ? 2 : (c == 7) ? 3 : -1; };
+    const int as_c = ALAT ? a_slot(col) : -1, as_r0 = ALAT ? a_slot(row[0]) : -1, as_r1 = ALAT ? a_slot(row[1]) : -1;
+    const double am0 = (as_c >= 0 && as_r0 >= 0) ? 1.0 : 0.0, am1 = (as_c >= 0 && as_r1 >= 0) ? 1.0 : 0.0;
+    const int ao_c = L.ha + max(as_c, 0), ao_r0 = L.ha + max(as_r0, 0), ao_r1 = L.ha + max(as_r1, 0);
     // K = Guu^-1 [G(u0,:); G(u1,:)]: lane group 0 holds (u0, u1) in the result registers (2, 3), group 1 holds (u1, u0)
     const double selA0 = (g == 0) ? 1.0 : 0.0, selA2 = (g == 1) ? 1.0 : 0.0, selB = (g < 2) ? -1.0 : 0.0;
 
@@ -231,11 +238,12 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
     // matrix instruction (before the stage's own LDS stores, whose addresses the compiler cannot tell apart), the arithmetic follows
     // once the transposed P has come back -- the reads' latency and the tile's round trip are covered by the stage's stores
     d4_t Hc;
-    double val[4], g10, g11, pg12 = 0.0, pg13 = 0.0, pa0 = 0.0, pa1 = 0.0;
+    double val[4], g10, g11, pg12 = 0.0, pg13 = 0.0, pa0 = 0.0, pa1 = 0.0, pg14 = 0.0, pac = 0.0, par0 = 0.0, par1 = 0.0;
     auto prepare_load = [&](const int k) {
         val[0] = sm[va[0]]; val[1] = sm[va[0] + 4]; val[2] = sm[va[0] + 8]; val[3] = sm[va[3]];      // rows g, g + 4, 8 + g; the mirrored input row
         g10 = sm[a_g10]; g11 = sm[a_g10 + 1];
         if (PATH) { pg12 = sm[a_g10 + 2]; pg13 = sm[a_g10 + 3]; pa0 = sm[L.hc + k * 2]; pa1 = sm[L.hc + k * 2 + 1]; }
+        if (ALAT) { pg14 = sm[a_g10 + 4]; pac = sm[ao_c + k * 4]; par0 = sm[ao_r0 + k * 4]; par1 = sm[ao_r1 + k * 4]; }
         a_g10 -= NCK;
         va[0] -= vstride[0]; va[3] -= vstride[3];
     };
@@ -255,6 +263,7 @@ __device__ __forceinline__ void riccati_sweep_mfma(const int N, const int lane, 
 #pragma unroll
         for (int r = 0; r < 4; r++) Hc[r] = fma(g11, c1k[r], fma(g10, c0k[r], fma(dsel[r], val[r], hk[r])));
         if (PATH) Hc[0] += p11 * (pg12 + pg13) + p12 * (pg12 * pa0 - pg13 * pa1) + p22 * (pg12 * pa0 * pa0 + pg13 * pa1 * pa1);
+        if (ALAT) { Hc[0] += am0 * pg14 * par0 * pac; Hc[1] += am1 * pg14 * par1 * pac; }
     };
     prepare_load(N - 1);
     prepare_compute(N - 1);

@@ -86,7 +86,10 @@ class AcadosModel:
     nu: int = NU
     np_: int = 3000
     # nonlinear path constraints h(x) of old/generate_acaods_interface.py:191-212: None, or "track" for the two
-    # track-boundary rows (right, left) at every stage and at the terminal stage (con_h_expr / con_h_expr_e there)
+    # track-boundary rows (right, left) at every stage and at the terminal stage (con_h_expr / con_h_expr_e there), or
+    # "track+a_lat" for the kinematic model's set (:198-209): the same two rows plus the lateral acceleration a_lat at the
+    # stages (lh, uh then have three entries: right, left, a_lat; lh_e, uh_e keep two).  The reference's T_dot and
+    # delta_dot rows of that set are linear in (x, u): they are the general rows C, D, lg, ug here (python/mpc.py:92-99)
     con_h_expr: str | None = None
     car_length: float = car_length
     car_width: float = car_width
@@ -327,6 +330,11 @@ class OcpData:
     soft_z: np.ndarray | None = None   # (N+1,28) linear slack penalty per one-sided constraint (14 lower, 14 upper)
     soft_Z: np.ndarray | None = None   # (N+1,28) quadratic slack penalty; < 0 = hard side
     path_on: int = 0                   # track-boundary rows h (stages 1..N)
+    alat_on: int = 0                   # lateral-acceleration row (stages 1..N-1, kinematic model): a fifteenth row beside the 14 of the tables
+    alat_lb: float = -INF
+    alat_ub: float = INF
+    alat_soft_z: np.ndarray | None = None   # (2) linear slack penalty of its lower / upper side
+    alat_soft_Z: np.ndarray | None = None   # (2) quadratic one; < 0 = hard side; None = both hard
     car_L: float = car_length
     car_W: float = car_width
     lh: np.ndarray = field(default_factory=lambda: np.full(NH, -INF))
@@ -380,14 +388,24 @@ class OcpData:
         cost = ocp.cost
         # nonlinear track rows: the same two rows at the stages and at the terminal stage
         path_on, lh, uh = 0, np.full(NH, -INF), np.full(NH, INF)
+        alat_on, alat_lb, alat_ub, alat_soft_z, alat_soft_Z = 0, -INF, INF, None, None
         if ocp.model.con_h_expr is not None:
-            if ocp.model.con_h_expr != "track":
-                raise ValueError("con_h_expr must be None or 'track'")
+            if ocp.model.con_h_expr not in ("track", "track+a_lat"):
+                raise ValueError("con_h_expr must be None, 'track' or 'track+a_lat'")
+            alat_on = int(ocp.model.con_h_expr == "track+a_lat")
             lh, uh = np.asarray(c.lh, dtype=float), np.asarray(c.uh, dtype=float)
-            if lh.shape != (NH,) or uh.shape != (NH,):
-                raise ValueError(f"lh, uh need {NH} entries (right, left track row)")
+            if lh.shape != (NH + alat_on,) or uh.shape != (NH + alat_on,):
+                raise ValueError(f"lh, uh need {NH + alat_on} entries (right, left track row" + (", a_lat)" if alat_on else ")"))
+            if alat_on:
+                if ocp.model.kind != "fkin6":
+                    raise ValueError("a_lat is a row of the kinematic model only (old/generate_acaods_interface.py:206)")
+                if o.nlp_solver_type != "SQP_RTI":
+                    raise ValueError("the a_lat row is implemented for SQP_RTI (old/generate.py:21)")
+                alat_lb = float(lh[2]) if abs(lh[2]) < 1e20 else -INF
+                alat_ub = float(uh[2]) if abs(uh[2]) < 1e20 else INF
+                lh, uh = lh[:NH], uh[:NH]
             if not (np.array_equal(lh, np.asarray(c.lh_e, dtype=float)) and np.array_equal(uh, np.asarray(c.uh_e, dtype=float))):
-                raise ValueError("lh_e, uh_e must equal lh, uh (old/generate_acaods_interface.py:411-449)")
+                raise ValueError("lh_e, uh_e must equal the track rows of lh, uh (old/generate_acaods_interface.py:411-449)")
             path_on = 1
         elif len(c.lh) or len(c.idxsh) or len(c.idxsh_e):
             raise ValueError("lh/uh/idxsh given but model.con_h_expr is None")
@@ -409,6 +427,14 @@ class OcpData:
             for j, pos in enumerate(np.asarray(c.idxsg, dtype=int)):
                 put(slice(0, N), 10 + int(pos), nsbx + j)
             for j, pos in enumerate(np.asarray(c.idxsh, dtype=int)):
+                if int(pos) == NH and alat_on:      # the a_lat row keeps its penalties beside the 28 columns
+                    if alat_soft_z is None:
+                        alat_soft_z, alat_soft_Z = np.zeros(2), np.full(2, -1.0)
+                    alat_soft_z[:] = cost.zl[nsbx + nsg + j], cost.zu[nsbx + nsg + j]
+                    alat_soft_Z[:] = cost.Zl[nsbx + nsg + j], cost.Zu[nsbx + nsg + j]
+                    continue
+                if not 0 <= int(pos) < NH:
+                    raise ValueError(f"idxsh position {int(pos)} names no row of con_h_expr")
                 put(slice(1, N), 12 + int(pos), nsbx + nsg + j)
             for j, pos in enumerate(np.asarray(c.idxsbx_e, dtype=int)):
                 put(N, int(idxe[pos]), j, "_e")
@@ -416,7 +442,7 @@ class OcpData:
                 put(N, 12 + int(pos), nsbx_e + j, "_e")
         return OcpData(
             soft_z=soft_z, soft_Z=soft_Z, path_on=path_on, car_L=float(ocp.model.car_length), car_W=float(ocp.model.car_width),
-            lh=lh, uh=uh,
+            lh=lh, uh=uh, alat_on=alat_on, alat_lb=alat_lb, alat_ub=alat_ub, alat_soft_z=alat_soft_z, alat_soft_Z=alat_soft_Z,
             N=N, M=int(o.sim_method_num_steps), dt=dt, model=ocp.model.model_id,
             integrator=integ, sim_integrator=sim_integ,
             cost_scale_stage=dt if o.cost_scale_stage is None else float(o.cost_scale_stage),
@@ -443,6 +469,8 @@ class OcpData:
         d["s_ref"] = np.atleast_2d(np.asarray(s_ref, dtype=float))
         d["kappa_ref"] = np.atleast_2d(np.asarray(kappa_ref, dtype=float))
         d["path_on"], d["car_L"], d["car_W"], d["lh"], d["uh"] = self.path_on, self.car_L, self.car_W, self.lh, self.uh
+        d["alat_on"], d["alat_lb"], d["alat_ub"] = self.alat_on, self.alat_lb, self.alat_ub
+        d["alat_soft_z"], d["alat_soft_Z"] = self.alat_soft_z, self.alat_soft_Z
         if self.path_on:
             if track_widths is None:
                 raise ValueError("track rows need track_widths (ntracks, 2) = (right, left)")

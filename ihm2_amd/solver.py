@@ -119,6 +119,18 @@ class BatchedOcpSolver:
         lh, uh = _f64(d.lh, (2,), "lh"), _f64(d.uh, (2,), "uh")
         _lib.check(self.lib.ihm2mpc_set_path_constraints(self._h, 1, float(d.car_L), float(d.car_W), _ptr(self._track_widths),
                                                          _ptr(lh), _ptr(uh)))
+        self._push_alat()
+
+    def _push_alat(self):
+        """The lateral-acceleration row of the kinematic constraint set (``old/generate_acaods_interface.py:198-209``)."""
+        d = self.data
+        if not getattr(d, "alat_on", 0):
+            _lib.check(self.lib.ihm2mpc_set_alat_constraint(self._h, 0, 0.0, 0.0, None, None))
+            return
+        z = None if d.alat_soft_z is None else _f64(d.alat_soft_z, (2,), "alat_soft_z")
+        Z = None if d.alat_soft_Z is None else _f64(d.alat_soft_Z, (2,), "alat_soft_Z")
+        _lib.check(self.lib.ihm2mpc_set_alat_constraint(self._h, 1, float(d.alat_lb), float(d.alat_ub), None if z is None else _ptr(z),
+                                                        None if Z is None else _ptr(Z)))
 
     def _push_soft(self):
         d = self.data
@@ -329,6 +341,17 @@ class BatchedOcpSolver:
         pi = np.empty((self.B, self.N + 1, NX)); lam = np.empty((self.B, self.N + 1, NLAM))
         _lib.check(self.lib.ihm2mpc_get_multipliers(self._h, _ptr(pi), _ptr(lam)))
         return pi, lam
+
+    def get_alat_multipliers(self):
+        """Multipliers and slack values of the lateral-acceleration row, ``(B, N+1, 2)`` each: lower side, upper side."""
+        lam = np.empty((self.B, self.N + 1, 2)); slk = np.empty((self.B, self.N + 1, 2))
+        _lib.check(self.lib.ihm2mpc_get_alat_multipliers(self._h, _ptr(lam), _ptr(slk)))
+        return lam, slk
+
+    def set_alat_multipliers(self, lam=None, slk=None):
+        la = None if lam is None else _f64(lam, (self.B, self.N + 1, 2), "lam")
+        sa = None if slk is None else _f64(slk, (self.B, self.N + 1, 2), "slk")
+        _lib.check(self.lib.ihm2mpc_set_alat_multipliers(self._h, None if la is None else _ptr(la), None if sa is None else _ptr(sa)))
 
     def set_slacks(self, sl=None):
         """Slack values the next SQP-mode solve starts from, ``(B, N+1, 28)``; ``None`` = zeros."""

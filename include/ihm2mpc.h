@@ -159,6 +159,21 @@ int ihm2mpc_set_soft(ihm2mpc_handle *h, const double *soft_z, const double *soft
  * enable = 0 removes the rows (the other arguments are then ignored and may be NULL). */
 int ihm2mpc_set_path_constraints(ihm2mpc_handle *h, int32_t enable, double car_length, double car_width,
                                  const double *widths, const double *lh, const double *uh);
+/* The lateral-acceleration row of the KINEMATIC model's nonlinear constraint set -- old/generate_acaods_interface.py:198-209
+ * (`[right, left, T_dot, delta_dot] + ([] if is_dynamic else [a_lat])`), bounds :52-53, :424, :433 (-5 / +5 m/s^2), definition :266-271 and
+ * old/scripts/gen_mpc.py:182-184, with the forces and the slip angle of python/models.py:255-263:
+ *     a_lat = (-F_Rx sin(beta) + F_Fx sin(delta - beta)) / m + (v_x^2 + v_y^2) sin(beta) / l_R ,   a_lat_min <= a_lat(x_k) <= a_lat_max
+ * on the stages 1..N-1 (x_0 is fixed; it is no terminal row: con_h_expr_e, :209-212), linearised at the iterate by every RTI step: a
+ * fifteenth row of a stage, with non-zeros in (v_x, v_y, T, delta).  soft_z, soft_Z (2 each: lower side, upper side; NULL = hard): slack
+ * penalties as ihm2mpc_set_soft (the reference softens every h row, :380-395).  Needs the kinematic OCP model, the track rows
+ * (ihm2mpc_set_path_constraints enabled), SQP_RTI and stage-independent weights; ihm2mpc_run_steps then launches per step.
+ * The row's multipliers and slack values do not change the 28-column layout of the other rows: (B,N+1,2) = (lower, upper) arrays of
+ * their own, zeroed by ihm2mpc_set_multipliers(.., NULL) / ihm2mpc_set_slacks(NULL) like the others.
+ * enable = 0 removes the row. */
+int ihm2mpc_set_alat_constraint(ihm2mpc_handle *h, int32_t enable, double a_lat_min, double a_lat_max, const double *soft_z,
+                                const double *soft_Z);
+int ihm2mpc_set_alat_multipliers(ihm2mpc_handle *h, const double *lam, const double *slk); /* (B,N+1,2) each; NULL = zero */
+int ihm2mpc_get_alat_multipliers(ihm2mpc_handle *h, double *lam, double *slk);             /* (B,N+1,2) each; either may be NULL */
 
 /* ---- per-instance data ---- */
 int ihm2mpc_set_x0(ihm2mpc_handle *h, const double *x0);         /* (B,8) */

@@ -32,8 +32,13 @@ extern "C" {
 #define ORC_NYE 8
 #define ORC_NG 2
 #define ORC_NH 2
-/* one-sided inequalities per stage: lower (8 bx, 2 bu, 2 g, 2 h) then upper (8, 2, 2, 2) */
+/* one-sided inequalities per stage: lower (8 bx, 2 bu, 2 g, 2 h) then upper (8, 2, 2, 2).
+ * A second build of the same sources with -DORC_NC=15 (libihm2_oracle_nc15.so, oracle/Makefile) carries the lateral-acceleration row of the
+ * kinematic constraint set (old/generate_acaods_interface.py:198-209) as row 14: every (.., ORC_NC, ..) and (.., 2 ORC_NC) array below is then
+ * 15 / 30 wide -- lower sides (8, 2, 2, 2, 1), then upper sides */
+#ifndef ORC_NC
 #define ORC_NC 14
+#endif
 #define ORC_NMAX 128
 
 /* FDYN6U: fdyn6 with every wheel's lateral force on its OWN slip angle; the reference crosses them (python/models.py:543-546,
@@ -89,6 +94,11 @@ typedef struct {
     double ipm_tol;  /* abs inf-norm tolerance on all four residual groups */
     double ipm_mu0;
     double ipm_tau0; /* lower clamp for initial slacks */
+    /* lateral-acceleration row (ORC_NC = 15 builds only; ignored otherwise), stages 1..N-1 of the kinematic model:
+     *   alat_lb <= a_lat(x_k) <= alat_ub ,  a_lat = (-F_Rx sin(beta) + F_Fx sin(delta - beta)) / m + (v_x^2 + v_y^2) sin(beta) / l_R
+     * old/generate_acaods_interface.py:198-209 (row), :266-271 and old/scripts/gen_mpc.py:182-184 (definition), :52-53 (bounds -5 / +5) */
+    int alat_on;
+    double alat_lb, alat_ub;
 } orc_problem;
 
 /* --- model (python/models.py:232-307 fkin6, :455-606 fdyn6) --- */
@@ -101,6 +111,10 @@ void orc_jac(int model, const double *x, const double *u, const double *s_ref, c
 /* same Jacobian by complex-step evaluation of the model formulas (both models) */
 void orc_jac_cs(int model, const double *x, const double *u, const double *s_ref, const double *kappa_ref,
                 int nknots, double *xdot, double *J);
+
+/* lateral acceleration of the kinematic model at x (8) and its gradient with respect to x (8; non-zeros in v_x, v_y, T, delta), by complex-step
+ * evaluation of the formula as the reference writes it (old/scripts/gen_mpc.py:182-184 with the forces of python/models.py:255-258) */
+double orc_alat(const double *x, double *grad);
 
 /* --- integrator: RK4 x M with forward sensitivities; A 8x8, Bm 8x2 row-major --- */
 void orc_rk4_sens(int model, int integrator, const double *x, const double *u, const double *s_ref,

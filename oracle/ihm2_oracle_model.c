@@ -148,6 +148,37 @@ static void fkin6_cs(const cplx *x, const cplx *u, const double *s_ref, const do
     f[7] = delta_dot;
 }
 
+/* ---- lateral acceleration of the kinematic model: the nonlinear row `a_lat` of old/generate_acaods_interface.py:198-209 ----
+ * definition old/generate_acaods_interface.py:266-271 = old/scripts/gen_mpc.py:182-184, on the forces and the slip angle of the live
+ * kinematic model (python/models.py:255-263) */
+static cplx alat_cs(const cplx *x)
+{
+    const double rwd = l_R / wheelbase;
+    cplx v_x = x[3], v_y = x[4], T = x[6], delta = x[7];
+    cplx F_motor = C_m0 * T;
+    cplx F_drag = -(C_r0 + C_r1 * v_x + C_r2 * v_x * v_x) * cs_smooth_sgn(v_x);
+    cplx F_Rx = 0.5 * F_motor + F_drag;
+    cplx F_Fx = 0.5 * F_motor;
+    cplx beta = cs_atan(rwd * cs_tan(delta));
+    cplx sinbeta = cs_sin(beta);
+    return (-F_Rx * sinbeta + F_Fx * cs_sin(delta - beta)) / m_ + (v_x * v_x + v_y * v_y) * sinbeta / l_R;
+}
+
+double orc_alat(const double *x, double *grad)
+{
+    const double hstep = 1e-30;
+    cplx xc[ORC_NX];
+    for (int i = 0; i < ORC_NX; i++) xc[i] = x[i];
+    const double val = creal(alat_cs(xc));
+    if (grad)
+        for (int j = 0; j < ORC_NX; j++) {
+            xc[j] = cs_make(x[j], hstep);
+            grad[j] = cimag(alat_cs(xc)) / hstep;
+            xc[j] = x[j];
+        }
+    return val;
+}
+
 /* ---- fdyn6 (python/models.py:455-606), explicit form via the 2x2 solve of SURVEY.md C.2 ---- */
 static void fdyn6_cs(const cplx *x, const cplx *u, const double *s_ref, const double *kappa_ref, int nk, cplx *f, int uncrossed)
 {

@@ -153,6 +153,17 @@ void orc_build_qp(const orc_problem *P, const double *x, const double *u, const 
                 if (fabs(P->uh[i]) < INF_BOUND) du[k * NC + 12 + i] = P->uh[i] - hval[i];
             }
         }
+#if ORC_NC > 14
+        /* row 14: the lateral-acceleration row of the kinematic model, stages 1..N-1 (no terminal row: con_h_expr_e has the track rows only,
+         * old/generate_acaods_interface.py:209-212; x_0 is fixed) */
+        if (P->alat_on && k >= 1 && k < N) {
+            double grad[NX];
+            const double aval = orc_alat(xk, grad);
+            for (int j = 0; j < NX; j++) R[(k * NC + 14) * NZ + j] = grad[j];
+            if (fabs(P->alat_lb) < INF_BOUND) dl[k * NC + 14] = P->alat_lb - aval;
+            if (fabs(P->alat_ub) < INF_BOUND) du[k * NC + 14] = P->alat_ub - aval;
+        }
+#endif
     }
     for (int i = 0; i < NX; i++) dx0[i] = x0[i] - x[i];
 }
@@ -293,12 +304,16 @@ static void constraint_gaps(const orc_problem *P, const double *x, const double 
             cv[12] = n + foot + lat - P->widths[tid * 2 + 0];
             cv[13] = -n - foot + lat - P->widths[tid * 2 + 1];
         }
+#if ORC_NC > 14
+        cv[14] = (P->alat_on && k >= 1 && k < N) ? orc_alat(xk, NULL) : 0.0;
+#endif
         for (int c = 0; c < NC; c++) {
             double lb = INFINITY, ub = INFINITY;     /* |bound| >= 1e20: absent */
             if (c < 8) { if (k >= 1) { lb = P->lbx[k * NX + c]; ub = P->ubx[k * NX + c]; } }
             else if (c < 10) { if (k < N) { lb = P->lbu[k * NU + c - 8]; ub = P->ubu[k * NU + c - 8]; } }
             else if (c < 12) { if (k < N) { lb = P->lg[k * ORC_NG + c - 10]; ub = P->ug[k * ORC_NG + c - 10]; } }
-            else if (P->path_on && k >= 1) { lb = P->lh[c - 12]; ub = P->uh[c - 12]; }
+            else if (c < 14) { if (P->path_on && k >= 1) { lb = P->lh[c - 12]; ub = P->uh[c - 12]; } }
+            else if (P->alat_on && k >= 1 && k < N) { lb = P->alat_lb; ub = P->alat_ub; }
             if (fabs(lb) < INF_BOUND) dl[k * NC + c] = lb - cv[c];
             if (fabs(ub) < INF_BOUND) du[k * NC + c] = ub - cv[c];
         }

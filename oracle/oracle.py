@@ -13,6 +13,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libihm2_oracle.so")
+# the same sources built with fifteen constraint rows per stage: row 14 = the lateral-acceleration row (ihm2_oracle.h, ORC_NC)
+_LIB15_PATH = os.path.join(_HERE, "libihm2_oracle_nc15.so")
 NX, NU, NZ, NY, NC, NG, NH = 8, 2, 10, 12, 14, 2, 2
 MODEL_FKIN6, MODEL_FDYN6, MODEL_FDYN6U, MODEL_KIN6, MODEL_DYN6 = 0, 1, 2, 3, 4
 INTEG_RK4 = 0
@@ -33,6 +35,7 @@ class _Problem(C.Structure):
         ("path_on", C.c_int), ("car_L", C.c_double), ("car_W", C.c_double), ("widths", _dp),
         ("lh", C.c_double * NH), ("uh", C.c_double * NH),
         ("ipm_iter_max", C.c_int), ("ipm_tol", C.c_double), ("ipm_mu0", C.c_double), ("ipm_tau0", C.c_double),
+        ("alat_on", C.c_int), ("alat_lb", C.c_double), ("alat_ub", C.c_double),
     ]
 
 
@@ -47,7 +50,7 @@ def build(force: bool = False) -> str:
     try:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     except (OSError, subprocess.CalledProcessError):
-        if force or not os.path.exists(_LIB_PATH):
+        if force or not (os.path.exists(_LIB_PATH) and os.path.exists(_LIB15_PATH)):
             raise
     return _LIB_PATH
 
@@ -63,7 +66,34 @@ def lib():
         _lib.orc_kappa.restype = C.c_double
         _lib.orc_qp_solve.restype = C.c_int
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_alat.restype = C.c_double
     return _lib
+
+
+_lib15 = None
+
+
+def lib15():
+    """The fifteen-row build (row 14 = lateral acceleration): arrays over the constraint rows are 15 / 30 wide there."""
+    global _lib15
+    if _lib15 is None:
+        build()
+        _lib15 = C.CDLL(_LIB15_PATH)
+        _lib15.orc_qp_solve.restype = C.c_int
+    return _lib15
+
+
+def alat(x):
+    """``a_lat`` of the kinematic model at x (8) and its gradient (8) -- ``orc_alat``."""
+    x, xp = _d(x)
+    g = np.zeros(NX)
+    return float(lib().orc_alat(xp, g.ctypes.data_as(_dp))), g
+
+
+def widen_rows(a28, a2):
+    """(.., 28) arrays over the fourteen rows + (.., 2) of the lateral-acceleration row -> the (.., 30) layout of the fifteen-row build."""
+    a28, a2 = np.asarray(a28), np.asarray(a2)
+    return np.concatenate([a28[..., :NC], a2[..., 0:1], a28[..., NC:], a2[..., 1:2]], axis=-1)
 
 
 def _d(a):
@@ -205,6 +235,10 @@ class OracleProblem:
     def __init__(self, desc: dict):
         self.N = int(desc["N"]); self.M = int(desc["M"])
         self._keep = {}
+        # the lateral-acceleration row: the fifteen-row build of the same sources; lam / sl arrays are then (.., 30) (widen_rows)
+        self.alat_on = int(desc.get("alat_on", 0))
+        self.nc = NC + 1 if self.alat_on else NC
+        self._lib = lib15() if self.alat_on else lib()
         p = _Problem()
         p.N = self.N; p.M = self.M; p.model = int(desc.get("model", 0)); p.integrator = int(desc.get("integrator", 0))
         p.dt = float(desc["dt"]); p.cost_scale_stage = float(desc["cost_scale_stage"])
@@ -217,10 +251,21 @@ class OracleProblem:
             a, ptr = _d(arr)
             self._keep[name] = a
             setattr(p, name, ptr)
-        if desc.get("soft_Z") is not None:
+        soft = {k: desc.get(k) for k in ("soft_z", "soft_Z")}
+        if self.alat_on:
+            p.alat_on = 1; p.alat_lb, p.alat_ub = float(desc["alat_lb"]), float(desc["alat_ub"])
+            if soft["soft_Z"] is not None or desc.get("alat_soft_Z") is not None:
+                N1 = self.N + 1
+                z28 = np.zeros((N1, 2 * NC)) if soft["soft_z"] is None else np.asarray(soft["soft_z"], dtype=np.float64)
+                Z28 = np.full((N1, 2 * NC), -1.0) if soft["soft_Z"] is None else np.asarray(soft["soft_Z"], dtype=np.float64)
+                az = np.zeros((N1, 2)); aZ = np.full((N1, 2), -1.0)
+                if desc.get("alat_soft_Z") is not None:
+                    az[1:self.N] = np.asarray(desc["alat_soft_z"], dtype=np.float64); aZ[1:self.N] = np.asarray(desc["alat_soft_Z"], dtype=np.float64)
+                soft = {"soft_z": widen_rows(z28, az), "soft_Z": widen_rows(Z28, aZ)}
+        if soft["soft_Z"] is not None:
             for name in ("soft_z", "soft_Z"):
-                a, ptr = _d(desc[name])
-                assert a.shape == (self.N + 1, 2 * NC)
+                a, ptr = _d(soft[name])
+                assert a.shape == (self.N + 1, 2 * self.nc)
                 self._keep[name] = a
                 setattr(p, name, ptr)
         p.path_on = int(desc.get("path_on", 0))
@@ -247,10 +292,10 @@ class OracleProblem:
         x0, x0p = _d(x0); yref, yp = _d(yref); yref_e, yep = _d(yref_e)
         tid, tp = _i(np.zeros(B, dtype=np.int32) if track_id is None else track_id)
         if pi is None: pi = np.zeros((B, N + 1, NX))
-        if lam is None: lam = np.zeros((B, N + 1, 2 * NC))
-        assert pi.flags.c_contiguous and lam.flags.c_contiguous
+        if lam is None: lam = np.zeros((B, N + 1, 2 * self.nc))
+        assert pi.flags.c_contiguous and lam.flags.c_contiguous and lam.shape[-1] == 2 * self.nc
         status = np.zeros(B, dtype=np.int32); res = np.zeros((B, 4)); qp_iter = np.zeros(B, dtype=np.int32)
-        lib().orc_rti_step(C.byref(self.p), C.c_int(B), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp), x0p, yp, yep, tp,
+        self._lib.orc_rti_step(C.byref(self.p), C.c_int(B), x.ctypes.data_as(_dp), u.ctypes.data_as(_dp), x0p, yp, yep, tp,
                            pi.ctypes.data_as(_dp), lam.ctypes.data_as(_dp), status.ctypes.data_as(_ip),
                            res.ctypes.data_as(_dp), qp_iter.ctypes.data_as(_ip), C.c_int(nthreads))
         return dict(status=status, res=res, qp_iter=qp_iter, pi=pi, lam=lam)
@@ -294,8 +339,9 @@ class OracleProblem:
         N = self.N
         x, xp = _d(x); u, up = _d(u); x0, x0p = _d(x0); yref, yp = _d(yref); yref_e, yep = _d(yref_e)
         H = np.zeros((N + 1, NZ, NZ)); g = np.zeros((N + 1, NZ)); A = np.zeros((N, NX, NX)); Bm = np.zeros((N, NX, NU))
-        b = np.zeros((N, NX)); dx0 = np.zeros(NX); R = np.zeros((N + 1, NC, NZ)); dl = np.zeros((N + 1, NC)); du = np.zeros((N + 1, NC))
-        lib().orc_build_qp(C.byref(self.p), xp, up, x0p, yp, yep, C.c_int(track_id), *[a.ctypes.data_as(_dp) for a in (H, g, A, Bm, b, dx0, R, dl, du)])
+        nc = self.nc
+        b = np.zeros((N, NX)); dx0 = np.zeros(NX); R = np.zeros((N + 1, nc, NZ)); dl = np.zeros((N + 1, nc)); du = np.zeros((N + 1, nc))
+        self._lib.orc_build_qp(C.byref(self.p), xp, up, x0p, yp, yep, C.c_int(track_id), *[a.ctypes.data_as(_dp) for a in (H, g, A, Bm, b, dx0, R, dl, du)])
         return dict(H=H, g=g, A=A, Bm=Bm, b=b, dx0=dx0, R=R, dl=dl, du=du)
 
     def sim_step(self, x, u, model, M, track_id=None, nthreads=0, integrator=INTEG_RK4):
