@@ -90,6 +90,7 @@ int ready(ihm2mpc_handle *h)
     if (!h->tracks_set) return fail("ihm2mpc_set_tracks has not been called");
     if (!h->weights_set) return fail("ihm2mpc_set_weights has not been called");
     if (!h->bounds_set) return fail("ihm2mpc_set_bounds has not been called");
+    if (!h->slots_fit) return fail("the constraint rows fit no QP kernel: at most 10 slots per lane of 64 (a two-sided hard row is one slot, a row with a soft side two), of which at most 4 soft; with soft sides the hard two-sided rows get 10 - 4 or 8 - 3 (8 - 2 without track rows) of them");
     if (h->alat_on) {
         // the row belongs to the kinematic constraint set of old/generate_acaods_interface.py:198-209, which comes with the track rows and SQP_RTI (old/generate.py:21)
         if (h->cfg.model != IHM2MPC_MODEL_FKIN6) return fail("the lateral-acceleration row is a row of the kinematic model (old/generate_acaods_interface.py:206: `[] if is_dynamic else [a_lat]`)");
@@ -175,7 +176,7 @@ int ihm2mpc_create(const ihm2mpc_config *cfg, ihm2mpc_handle **out)
     DA(slot_kc_blk, 1024); DA(slot_lb_blk, 1024); DA(slot_ub_blk, 1024);
     DA(slot_kc, MAX_SLOTS); DA(slot_lb, MAX_SLOTS); DA(slot_ub, MAX_SLOTS); DA(slot_zw, MAX_SLOTS); DA(slot_Zw, MAX_SLOTS);
     DA(slk, B * NS * NLAM); DA(widths, (size_t)cfg->ntracks * 2); DA(lam_a, B * NS * 2); DA(slk_a, B * NS * 2);
-    h->alat_on = 0; h->alat_lb = -INFINITY; h->alat_ub = INFINITY; h->alat_sz[0] = h->alat_sz[1] = 0.0; h->alat_sZ[0] = h->alat_sZ[1] = -1.0;
+    h->alat_on = 0; h->slots_fit = true; h->alat_lb = -INFINITY; h->alat_ub = INFINITY; h->alat_sz[0] = h->alat_sz[1] = 0.0; h->alat_sZ[0] = h->alat_sZ[1] = -1.0;
     DA(X_ref, (size_t)cfg->ntracks * cfg->nknots); DA(Y_ref, (size_t)cfg->ntracks * cfg->nknots); DA(phi_ref, (size_t)cfg->ntracks * cfg->nknots);
     DA(xc, B * 8); DA(s_guess, B);
     DA(step_args, 32);
@@ -397,52 +398,101 @@ int ihm2mpc_set_weights(ihm2mpc_handle *h, const double *W, const double *W_e)
 // Constraint-slot table of the QP kernel.  A slot is a (stage, row) pair with its finite sides; a row with a SOFT
 // side is split into one-sided slots (the slack belongs to one side).  Lane `l` of the instance's wavefront owns the
 // entries l, l+64, ...; both halves of a split row go to the same lane (they accumulate into the same LDS words
-// without atomics) and a lane's soft slots come first (the kernel keeps slack registers for the first NSOFT only).
+// without atomics).  Tables with soft sides: the first S entries of a lane hold ONE-SIDED slots only -- its soft ones first, then hard
+// one-sided ones, else padding -- where S is the NSOFT of the kernel instantiation that will run the table: the kernel keeps slack
+// registers, and one side's registers only, for those (kernels_qp.hip: ONE_SIDED).  All-hard tables: every entry may be two-sided (S = 0).
 static int rebuild_slots(ihm2mpc_handle *h)
 {
     const int NS = h->NS;
     struct Slot { int kc; double lb, ub, zw, Zw; };
+    struct Row { int kc; double lb, ub, szl, sZl, szu, sZu; bool fl, fu, sl, su; };
+    // the rows with a finite side, stage-major (row 14: the lateral-acceleration row of the stages 1..N-1, kept beside the NC = 14 rows of the tables)
+    std::vector<Row> rows;
+    int m_act = 0, soft_total = 0;
+    for (int k = 0; k < NS; k++)
+        for (int c = 0; c < NC + 1; c++) {
+            const bool extra = c == NC;
+            if (extra && !(h->alat_on && k >= 1 && k < NS - 1)) continue;
+            Row r;
+            r.kc = k * 16 + c;
+            r.lb = extra ? h->alat_lb : h->host_lb[k * NC + c]; r.ub = extra ? h->alat_ub : h->host_ub[k * NC + c];
+            r.fl = std::isfinite(r.lb); r.fu = std::isfinite(r.ub);
+            if (!r.fl && !r.fu) continue;
+            r.szl = extra ? h->alat_sz[0] : h->host_sz[k * NLAM + c]; r.sZl = extra ? h->alat_sZ[0] : h->host_sZ[k * NLAM + c];
+            r.szu = extra ? h->alat_sz[1] : h->host_sz[k * NLAM + NC + c]; r.sZu = extra ? h->alat_sZ[1] : h->host_sZ[k * NLAM + NC + c];
+            r.sl = r.fl && r.sZl >= 0.0; r.su = r.fu && r.sZu >= 0.0;
+            rows.push_back(r);
+            soft_total += (int)r.sl + (int)r.su;
+            m_act += (int)r.fl + (int)r.fu + (int)r.sl + (int)r.su;
+        }
+    // (NSOFT, NSLOT) of the kernel instantiations that take this kind of table, in the launchers' order (kernels_qp.hip)
+    struct Cand { int S, NSL; };
+    std::vector<Cand> cands;
+    if (soft_total == 0) cands = {{0, 8}};
+    else if (h->alat_on) cands = {{4, 10}};
+    else if (h->path_on) cands = {{3, 8}, {4, 10}};
+    else cands = {{2, 8}, {4, 10}};
     std::vector<Slot> lanes[64];
-    int nsoft[64] = {0};
-    int m_act = 0, total = 0;
-    // two passes: rows with a soft side first, spread by soft count, then the hard rows by total count
-    // (row 14: the lateral-acceleration row of the stages 1..N-1, kept beside the NC = 14 rows of the tables)
-    for (int pass = 0; pass < 2; pass++)
-        for (int k = 0; k < NS; k++)
-            for (int c = 0; c < NC + 1; c++) {
-                const bool extra = c == NC;
-                if (extra && !(h->alat_on && k >= 1 && k < NS - 1)) continue;
-                const double lb = extra ? h->alat_lb : h->host_lb[k * NC + c], ub = extra ? h->alat_ub : h->host_ub[k * NC + c];
-                const bool fl = std::isfinite(lb), fu = std::isfinite(ub);
-                if (!fl && !fu) continue;
-                const double szl = extra ? h->alat_sz[0] : h->host_sz[k * NLAM + c], sZl = extra ? h->alat_sZ[0] : h->host_sZ[k * NLAM + c];
-                const double szu = extra ? h->alat_sz[1] : h->host_sz[k * NLAM + NC + c], sZu = extra ? h->alat_sZ[1] : h->host_sZ[k * NLAM + NC + c];
-                const bool sl = fl && sZl >= 0.0, su = fu && sZu >= 0.0;
-                if ((sl || su) != (pass == 0)) continue;
-                int best = 0;       // least-loaded lane; ties -> lowest lane (round-robin for an all-hard table)
+    int per_lane = 0, soft_lane = 0, total = 0, S_used = 0;
+    bool placed = false;
+    for (const Cand &cd : cands) {
+        const int S = cd.S;
+        std::vector<Slot> ones[64], twos[64];       // one-sided slots (soft ones first), two-sided slots
+        int nsoft[64] = {0};
+        auto tail = [&](int l) { return (int)twos[l].size() + std::max(0, (int)ones[l].size() - S); };     // entries behind the first S
+        // two passes: rows with a soft side first, spread by soft count, then the hard rows by the entries behind the leading ones
+        // (all-hard tables, S = 0: by total count -- round-robin)
+        for (int pass = 0; pass < 2; pass++)
+            for (const Row &r : rows) {
+                if ((r.sl || r.su) != (pass == 0)) continue;
+                int best = 0;       // least-loaded lane; ties -> lowest lane
                 for (int l = 1; l < 64; l++) {
                     const bool fewer_soft = nsoft[l] < nsoft[best], same_soft = nsoft[l] == nsoft[best];
-                    const bool fewer = lanes[l].size() < lanes[best].size();
+                    const int tl = tail(l) + ((S > 0 && pass == 1 && !(r.fl && r.fu) && (int)ones[l].size() < S) ? -1 : 0);
+                    const int tb = tail(best) + ((S > 0 && pass == 1 && !(r.fl && r.fu) && (int)ones[best].size() < S) ? -1 : 0);
+                    const bool fewer = (pass == 0) ? ones[l].size() + twos[l].size() < ones[best].size() + twos[best].size() : tl < tb;
                     if (pass == 0 ? (fewer_soft || (same_soft && fewer)) : fewer) best = l;
                 }
-                std::vector<Slot> &L = lanes[best];
-                if (!sl && !su) L.push_back({k * 16 + c, lb, ub, 0.0, -1.0});
-                else {
-                    if (fl) L.push_back({k * 16 + c, lb, INFINITY, sl ? szl : 0.0, sl ? sZl : -1.0});
-                    if (fu) L.push_back({k * 16 + c, -INFINITY, ub, su ? szu : 0.0, su ? sZu : -1.0});
+                if (!r.sl && !r.su) {
+                    if (S > 0 && !(r.fl && r.fu)) ones[best].push_back({r.kc, r.lb, r.ub, 0.0, -1.0});     // a hard one-sided row may lead
+                    else twos[best].push_back({r.kc, r.lb, r.ub, 0.0, -1.0});
+                } else {
+                    // the soft half in front of a hard half
+                    Slot lo = {r.kc, r.lb, INFINITY, r.sl ? r.szl : 0.0, r.sl ? r.sZl : -1.0}, up = {r.kc, -INFINITY, r.ub, r.su ? r.szu : 0.0, r.su ? r.sZu : -1.0};
+                    if (r.fl && r.sl) ones[best].push_back(lo);
+                    if (r.fu && r.su) ones[best].push_back(up);
+                    if (r.fl && !r.sl) ones[best].push_back(lo);
+                    if (r.fu && !r.su) ones[best].push_back(up);
                 }
-                nsoft[best] += (int)sl + (int)su;
-                m_act += (int)fl + (int)fu + (int)sl + (int)su;
+                nsoft[best] += (int)r.sl + (int)r.su;
             }
-    int per_lane = 0, soft_lane = 0;
-    for (int l = 0; l < 64; l++) {
-        std::stable_partition(lanes[l].begin(), lanes[l].end(), [](const Slot &s) { return s.Zw >= 0.0; });
-        per_lane = std::max(per_lane, (int)lanes[l].size());
-        soft_lane = std::max(soft_lane, nsoft[l]);
-        total += (int)lanes[l].size();
+        int pl = 0, sl_max = 0;
+        for (int l = 0; l < 64; l++) {
+            std::stable_partition(ones[l].begin(), ones[l].end(), [](const Slot &s) { return s.Zw >= 0.0; });
+            pl = std::max(pl, S + tail(l));
+            sl_max = std::max(sl_max, nsoft[l]);
+        }
+        if (soft_total > 0 && (sl_max > S || pl > cd.NSL)) continue;
+        // lay the lanes out: S leading one-sided entries (padding where a lane has fewer), then the rest
+        total = 0;
+        for (int l = 0; l < 64; l++) {
+            lanes[l].clear();
+            const int lead = std::min(S, (int)ones[l].size());
+            for (int i = 0; i < lead; i++) lanes[l].push_back(ones[l][i]);
+            if (!twos[l].empty() || (int)ones[l].size() > S)
+                for (int i = lead; i < S; i++) lanes[l].push_back({-1, -INFINITY, INFINITY, 0.0, -1.0});
+            for (size_t i = S; i < ones[l].size(); i++) lanes[l].push_back(ones[l][i]);
+            for (const Slot &t : twos[l]) lanes[l].push_back(t);
+            for (const Slot &t : lanes[l]) total += t.kc >= 0;
+        }
+        per_lane = 0;
+        for (int l = 0; l < 64; l++) per_lane = std::max(per_lane, (int)lanes[l].size());
+        soft_lane = sl_max; S_used = S; placed = true;
+        break;
     }
-    if (per_lane * 64 > MAX_SLOTS || soft_lane > 4)
-        return fail("%d constraint slots per lane (%d soft) exceed the QP kernel limits (10 per lane, 4 soft)", per_lane, soft_lane);
+    h->slots_fit = placed && per_lane * 64 <= MAX_SLOTS && soft_lane <= 4;
+    if (!h->slots_fit) return 0;        // ready() reports it: the setters come one by one and a later one may make the rows fit
+    if (soft_total > 0) soft_lane = S_used;      // what the launchers select the instantiation by: its NSOFT
     const size_t n = (size_t)per_lane * 64;
     std::vector<int32_t> kc(n, -1);
     std::vector<double> slb(n, -INFINITY), sub(n, INFINITY), zw(n, 0.0), Zw(n, -1.0);

@@ -51,7 +51,8 @@ struct ihm2mpc_handle {
     // compact table of the constraint slots that have at least one finite side
     // -- laid out for the QP kernel: entry lane + 64 r belongs to lane `lane`; a lane's soft slots come first --
     int nslots, m_act;             // m_act: number of one-sided inequality pairs (finite sides + one per soft slack)
-    int nslot_lane, nsoft_lane;    // slots per lane / soft slots per lane (maxima over the 64 lanes)
+    int nslot_lane, nsoft_lane;    // slots per lane / leading one-sided entries per lane (the NSOFT of the instantiation that takes the table; 0: all-hard)
+    bool slots_fit;                // false: the rows set so far fit no instantiation (reported by the next solve: a later setter may still change them)
     int32_t *slot_kc;              // (nslot_lane*64) stage * 16 + row, -1 = padding
     int32_t *slot_kc_blk;          // the same rows spread over 256 lanes (k_qp_block: four wavefronts per instance), all-hard tables only
     double *slot_lb_blk, *slot_ub_blk;

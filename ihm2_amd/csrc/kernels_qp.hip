@@ -427,6 +427,21 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #pragma unroll
     for (int r = 0; r < NSO; r++) { so_zw[r] = 0.0; so_Zw[r] = -1.0; so_s[r] = 1.0; so_ls[r] = 0.0; so_rs[r] = 0.0; so_ds[r] = so_dls[r] = so_pa[r] = 0.0; }
 #define IS_SOFT(r) ((r) < NSOFT && so_Zw[(r) < NSOFT ? (r) : 0] >= 0.0)
+// The first NSOFT slots of a lane are ONE-SIDED by construction of the table (api.hip: rebuild_slots puts a lane's one-sided slots -- the soft
+// ones first -- there and nothing else): they live in the lower side's registers alone, an upper side as the lower side of the negated row
+// (s_sg = -1: -R z >= -ub), and the upper side's seven registers per slot are never touched.  (The soft instantiations are register-bound:
+// 648 B of scratch per lane in `<8,3,1,1>` before this.)
+// (not in the PATH == 2 instantiation: `k_qp_wave<10,4,2,1>` in this form returned wrong statuses when built with LLVM's iterative ILP
+// scheduler -- run to run different ones -- while the default build matched the CPU restatement on 4096 instances; the cause was not found
+// (NOTES.md R4.10), so that kernel keeps both sides' registers for every slot, the form that passes in both builds)
+#define ONE_SIDED(r) (NSOFT > 0 && PATH != 2 && (r) < NSOFT)
+#define HAS_L(r) (ONE_SIDED(r) ? true : fin(s_dl[r]))
+#define HAS_U(r) (ONE_SIDED(r) ? false : fin(s_du[r]))
+#define ROW_DOT(r, v) (ONE_SIDED(r) ? s_sg[(r) < NSOFT ? (r) : 0] * row_dot(s_kc[r], (v)) : row_dot(s_kc[r], (v)))
+#define ROW_SIGN(r, c) (ONE_SIDED(r) ? s_sg[(r) < NSOFT ? (r) : 0] * (c) : (c))
+    double s_sg[NSO];
+#pragma unroll
+    for (int r = 0; r < NSO; r++) s_sg[r] = 1.0;
 // rows are split (two slots, one lane, one LDS word) only when soft sides exist
 #define SLOT_ACC(dst, v) do { if (NSOFT > 0) (dst) += (v); else (dst) = (v); } while (0)
     double r_ineq = 0.0, r_comp = 0.0;
@@ -463,6 +478,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             const double lam_in_l = (ALAT && c == 14) ? lamab[k * 2] : lamb[k * 28 + c], lam_in_u = (ALAT && c == 14) ? lamab[k * 2 + 1] : lamb[k * 28 + 14 + c];
             if (fin(lb)) { s_dl[r] = lb - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, s_dl[r]); r_comp = fmax(r_comp, fabs(lam_in_l * s_dl[r])); } }
             if (fin(ubd)) { s_du[r] = ubd - cz; if (want_res && !soft) { r_ineq = fmax(r_ineq, -s_du[r]); r_comp = fmax(r_comp, fabs(lam_in_u * s_du[r])); } }
+            if (ONE_SIDED(r) && fin(ubd)) { s_sg[r < NSOFT ? r : 0] = -1.0; s_dl[r] = -s_du[r]; }      // R z <= ub  as  -R z >= -ub
         }
     }
     if (want_res) { r_stat = blk_max(r_stat); r_eq = blk_max(r_eq); r_ineq = blk_max(r_ineq); r_comp = blk_max(r_comp); }
@@ -496,8 +512,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #pragma unroll
     for (int r = 0; r < NSLOT; r++) {
         if (s_kc[r] < 0) continue;
-        const double rz = row_dot(s_kc[r], z);
-        const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+        const double rz = ROW_DOT(r, z);
+        const bool al = HAS_L(r), au = HAS_U(r);
         double tau_c = a.tau0;
         if (al && au) tau_c = fmin(a.tau0, 0.25 * (s_du[r] - s_dl[r]));
         if (IS_SOFT(r)) {
@@ -529,8 +545,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
                 if (s_kc[r] < 0) continue;
-                const bool al = fin(s_dl[r]), au = fin(s_du[r]);
-                SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));     // the two halves of a split slot share a lane
+                const bool al = HAS_L(r), au = HAS_U(r);
+                SLOT_ACC(cf[s_kc[r]], ROW_SIGN(r, (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0)));     // the two halves of a split slot share a lane
             }
             BSYNC();
         };
@@ -547,8 +563,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         for (int r = 0; r < NSLOT; r++) {
             rd_l[r] = rd_u[r] = 0.0;
             if (s_kc[r] < 0) continue;
-            const double rz = row_dot(s_kc[r], z);
-            const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+            const double rz = ROW_DOT(r, z);
+            const bool al = HAS_L(r), au = HAS_U(r);
             const double sv = IS_SOFT(r) ? so_s[r < NSOFT ? r : 0] : 0.0;      // the slack enters its (single) side
             // (the complementarity products are summed as rounded products, in slot order: the sum is then the same number whichever
             // lanes hold the slots -- one wave per instance or four, SLOT_SUM below)
@@ -563,7 +579,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 res_gs = nanmax(res_gs, fabs(so_rs[q]));
                 mu_acc += so_ls[q] * so_s[q]; res_m = nanmax(res_m, fabs(so_ls[q] * so_s[q]));
             }
-            if (LEAN == 0) SLOT_ACC(cf[s_kc[r]], (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0));
+            if (LEAN == 0) SLOT_ACC(cf[s_kc[r]], ROW_SIGN(r, (al ? lam_l[r] : 0.0) - (au ? lam_u[r] : 0.0)));
         }
         if constexpr (NW > 1) {
             // several waves per instance: the slots' terms go to LDS (gam: dead between the factor sweep and the next coefficient phase) and every wave
@@ -667,7 +683,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #pragma unroll
             for (int r = 0; r < NSLOT; r++) {
                 if (s_kc[r] < 0) continue;
-                const bool al = fin(s_dl[r]), au = fin(s_du[r]);
+                const bool al = HAS_L(r), au = HAS_U(r);
                 double c = 0.0;
                 if (IS_SOFT(r)) {
                     // eliminated slack block: gamma_eff = gam (Z + gam_s)/D, coef_eff = c1 - gam (rs + c1 + c2)/D
@@ -678,7 +694,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     if (pass == 0) { c1 = (lm * tt + lm * rdv) / tt; c2 = so_ls[q]; rsv = so_rs[q]; gam[s_kc[r]] += gm * (so_Zw[q] + gs) / D; }
                     else { c1 = ((al ? pa_l[r] : pa_u[r]) - mu_t) / tt; c2 = (so_pa[q] - mu_t) / so_s[q]; rsv = 0.0; }
                     c = c1 - gm * (rsv + c1 + c2) / D;
-                    cf[s_kc[r]] += al ? c : -c;
+                    cf[s_kc[r]] += ONE_SIDED(r) ? ROW_SIGN(r, c) : (al ? c : -c);
                     continue;
                 }
                 if (pass == 0) {
@@ -691,7 +707,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     if (al) c += (pa_l[r] - mu_t) / t_l[r];
                     if (au) c -= (pa_u[r] - mu_t) / t_u[r];
                 }
-                SLOT_ACC(cf[s_kc[r]], c);
+                SLOT_ACC(cf[s_kc[r]], ROW_SIGN(r, c));
             }
             BSYNC();
         };
@@ -918,10 +934,10 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
             for (int r = 0; r < NSLOT; r++) {
                 dlam_l[r] = dlam_u[r] = dt_l[r] = dt_u[r] = 0.0;
                 if (s_kc[r] < 0) continue;
-                const double drz = row_dot(s_kc[r], dz);
+                const double drz = ROW_DOT(r, dz);
                 if (IS_SOFT(r)) {
                     const int q = r < NSOFT ? r : 0;
-                    const bool al = fin(s_dl[r]);
+                    const bool al = HAS_L(r);
                     const double lm = al ? lam_l[r] : lam_u[r], tt = al ? t_l[r] : t_u[r], rdv = al ? rd_l[r] : rd_u[r];
                     const double y = al ? drz : -drz;
                     const double gm = lm / tt, gs = so_ls[q] / so_s[q], D = so_Zw[q] + gm + gs;
@@ -940,7 +956,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                     if (dlv < 0.0) amax_d = fmin(amax_d, -lm / dlv);
                     continue;
                 }
-                if (fin(s_dl[r])) {
+                if (HAS_L(r)) {
                     const double rm = (pass == 0) ? lam_l[r] * t_l[r] : lam_l[r] * t_l[r] + pa_l[r] - mu_t;
                     dt_l[r] = drz + rd_l[r];
                     if (NSOFT == 0) {       // all-hard tables: one reciprocal per side, step bound as 1 / max(-dt / t)
@@ -954,7 +970,7 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                         if (dlam_l[r] < 0.0) amax_d = fmin(amax_d, -lam_l[r] / dlam_l[r]);
                     }
                 }
-                if (fin(s_du[r])) {
+                if (HAS_U(r)) {
                     const double rm = (pass == 0) ? lam_u[r] * t_u[r] : lam_u[r] * t_u[r] + pa_u[r] - mu_t;
                     dt_u[r] = -drz + rd_u[r];
                     if (NSOFT == 0) {
@@ -979,8 +995,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
                 for (int r = 0; r < NSLOT; r++) {
                     pa_l[r] = dlam_l[r] * dt_l[r]; pa_u[r] = dlam_u[r] * dt_u[r];
                     if (s_kc[r] < 0) continue;
-                    mu_aff = __dadd_rn(mu_aff, __dadd_rn(fin(s_dl[r]) ? __dmul_rn(fma(amax_d, dlam_l[r], lam_l[r]), fma(amax, dt_l[r], t_l[r])) : 0.0,
-                                                         fin(s_du[r]) ? __dmul_rn(fma(amax_d, dlam_u[r], lam_u[r]), fma(amax, dt_u[r], t_u[r])) : 0.0));
+                    mu_aff = __dadd_rn(mu_aff, __dadd_rn(HAS_L(r) ? __dmul_rn(fma(amax_d, dlam_l[r], lam_l[r]), fma(amax, dt_l[r], t_l[r])) : 0.0,
+                                                         HAS_U(r) ? __dmul_rn(fma(amax_d, dlam_u[r], lam_u[r]), fma(amax, dt_u[r], t_u[r])) : 0.0));
                     if (IS_SOFT(r)) {
                         const int q = r < NSOFT ? r : 0;
                         so_pa[q] = so_dls[q] * so_ds[q];
@@ -1055,8 +1071,8 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
 #pragma unroll
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
-            if (fin(s_dl[r])) { lam_l[r] = fma(alpha_d, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
-            if (fin(s_du[r])) { lam_u[r] = fma(alpha_d, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
+            if (HAS_L(r)) { lam_l[r] = fma(alpha_d, dlam_l[r], lam_l[r]); t_l[r] = fma(alpha, dt_l[r], t_l[r]); }
+            if (HAS_U(r)) { lam_u[r] = fma(alpha_d, dlam_u[r], lam_u[r]); t_u[r] = fma(alpha, dt_u[r], t_u[r]); }
             if (IS_SOFT(r)) { const int q = r < NSOFT ? r : 0; so_s[q] = fma(alpha, so_ds[q], so_s[q]); so_ls[q] = fma(alpha_d, so_dls[q], so_ls[q]); }
         }
         BSYNC();
@@ -1093,6 +1109,12 @@ __device__ __forceinline__ void qp_wave_body(const QpArgs &a, const int b, doubl
         for (int r = 0; r < NSLOT; r++) {
             if (s_kc[r] < 0) continue;
             const int k = s_kc[r] / NCK, c = s_kc[r] % NCK;
+            if (ONE_SIDED(r)) {        // the one side, kept in the lower side's registers: s_sg < 0 = it is the row's upper side
+                const int up = (s_sg[r < NSOFT ? r : 0] < 0.0) ? 1 : 0;
+                if (ALAT && c == 14) { lamab[k * 2 + up] = lam_l[r]; if (IS_SOFT(r)) slkab[k * 2 + up] = so_s[r < NSOFT ? r : 0]; }
+                else { lamb[k * 28 + 14 * up + c] = lam_l[r]; if (IS_SOFT(r)) slkb[k * 28 + 14 * up + c] = so_s[r < NSOFT ? r : 0]; }
+                continue;
+            }
             if (ALAT && c == 14) {
                 if (fin(s_dl[r])) lamab[k * 2] = lam_l[r];
                 if (fin(s_du[r])) lamab[k * 2 + 1] = lam_u[r];
@@ -1419,7 +1441,7 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
     if (irk && !(h->irk_tab && h->uniform_H && h->uniform_CD && (h->cfg.nlp_solver_type != IHM2MPC_SQP || !h->sqp_globalization || h->ls_phi))) return 1;
     const bool sqp = h->cfg.nlp_solver_type == IHM2MPC_SQP;
     if (sqp && !h->ls_x) return 1;        // the caller allocates the line-search buffers first
-    const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8;
+    const bool hard = !h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 10;
 #if QP_SET == 0
     if (!hard) return ihm2_launch_steps_soft(h, model, M_sim, s_target, n_steps, freeze, lap_stop, hist_u0, hist_x0, hist_st, hist_it);
 #elif QP_SET == 1
@@ -1484,7 +1506,15 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
 #if QP_SET != 1
     if (hard) {
         if (h->nslot_lane <= 5) { if (uni) LAUNCH_STEPS(5, 0, 0, 1); else LAUNCH_STEPS(5, 0, 0, 0); }
-        else { if (uni) LAUNCH_STEPS(8, 0, 0, 1); else LAUNCH_STEPS(8, 0, 0, 0); }
+        else if (h->nslot_lane <= 8) { if (uni) LAUNCH_STEPS(8, 0, 0, 1); else LAUNCH_STEPS(8, 0, 0, 0); }
+        else {      // long horizons (N <= 79 at 8 rows per stage): kinematic model, batch-shared tables
+#if QP_SET == 0
+            if (!uni) return 1;
+            LAUNCH_STEPS(10, 0, 0, 1);
+#else
+            return 1;
+#endif
+        }
     }
 #endif
 #if QP_SET != 0
@@ -1497,7 +1527,8 @@ int ihm2_launch_steps_dyn(ihm2mpc_handle *h, int model, int M_sim, double s_targ
             else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 0, 1);
             else return 1;
         } else {
-            if (nsoft <= 2 && per_lane <= 8) LAUNCH_STEPS(8, 2, 1, 1);
+            // (the NSOFT of an instantiation = the leading ONE-SIDED entries of a lane, api.hip::rebuild_slots: an all-hard table takes NSOFT = 0)
+            if (nsoft == 0) { if (per_lane <= 8) LAUNCH_STEPS(8, 0, 1, 1); else return 1; }
             else if (nsoft <= 3 && per_lane <= 8) LAUNCH_STEPS(8, 3, 1, 1);
             else if (nsoft <= 4 && per_lane <= 10) LAUNCH_STEPS(10, 4, 1, 1);
             else return 1;
@@ -1518,7 +1549,7 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
 #endif
 {
 #if QP_SET == 1
-    if (!h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 8) return ihm2_launch_qp_hard(h);
+    if (!h->path_on && h->nsoft_lane == 0 && h->nslot_lane <= 10) return ihm2_launch_qp_hard(h);
 #endif
     QpArgs a = qp_args(h);
     const int uni = h->uniform_H && h->uniform_CD;
@@ -1550,19 +1581,25 @@ int ihm2_launch_qp(ihm2mpc_handle *h)
     }
     if (nsoft == 0 && per_lane <= 5) LAUNCH_QP(5, 0, 0);
     else if (nsoft == 0 && per_lane <= 8) LAUNCH_QP(8, 0, 0);
+    else if (nsoft == 0 && per_lane <= 10) LAUNCH_QP(10, 0, 0);
     else return 2;
 #else
     if (h->alat_on) {
         // track rows + the lateral-acceleration row (ready() has checked: kinematic model, track rows on, batch-shared tables)
-        if (!uni || !h->path_on || nsoft > 4 || per_lane > 10) return 2;
-        (void)hipFuncSetAttribute((const void *)k_qp_wave<10, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_qp_wave<10, 4, 2, 1>), dim3(h->B), dim3(64), lds, h->stream, a);
+        if (!uni || !h->path_on || nsoft > 4 || per_lane > 10 || (nsoft == 0 && per_lane > 8)) return 2;
+        if (nsoft == 0) {       // all sides hard
+            (void)hipFuncSetAttribute((const void *)k_qp_wave<8, 0, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_qp_wave<8, 0, 2, 1>), dim3(h->B), dim3(64), lds, h->stream, a);
+        } else {
+            (void)hipFuncSetAttribute((const void *)k_qp_wave<10, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_qp_wave<10, 4, 2, 1>), dim3(h->B), dim3(64), lds, h->stream, a);
+        }
     } else if (!h->path_on) {
         if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 0);
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 0);
         else return 2;
     } else {
-        if (nsoft <= 2 && per_lane <= 8) LAUNCH_QP(8, 2, 1);
+        if (nsoft == 0) { if (per_lane <= 8) LAUNCH_QP(8, 0, 1); else return 2; }
         else if (nsoft <= 3 && per_lane <= 8) LAUNCH_QP(8, 3, 1);
         else if (nsoft <= 4 && per_lane <= 10) LAUNCH_QP(10, 4, 1);
         else return 2;

@@ -495,8 +495,10 @@ def test_misuse_of_the_extended_abi_is_reported(track):
     Z[3, 1] = 1.0; z[3, 1] = -1.0                             # decreasing linear penalty
     with pytest.raises(_lib.Ihm2mpcError):
         s.set_soft(z, Z)
-    with pytest.raises(_lib.Ihm2mpcError):                   # too many soft sides for the kernel's slack registers
-        s.set_soft(np.ones((N + 1, 28)), np.ones((N + 1, 28)))
+    # too many soft sides for the kernel's slack registers: reported by the next solve (the setters come one by one, a later one may make the rows fit)
+    s.set_soft(np.ones((N + 1, 28)), np.ones((N + 1, 28)))
+    with pytest.raises(_lib.Ihm2mpcError, match="fit no QP kernel"):
+        s.solve()
     s.set_soft(None, None)
     lh, uh, w = np.array([0.0, 0.0]), np.array([-1.0, 0.0]), np.array([[1.5, 1.5]])
     c_dp = _lib.c_double_p
