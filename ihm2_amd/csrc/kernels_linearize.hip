@@ -103,6 +103,22 @@ __global__ __launch_bounds__(64) void k_linearize_cols(int B, int N, int M, doub
     }
 }
 
+// columns of the dynamic models' stage derivatives dK parked in LDS between the stages (k_linearize_dyn), and their positions there
+#ifndef DK_PARK_FROM
+#define DK_PARK_FROM 7
+#endif
+__host__ __device__ constexpr int dk_pos(int c, int i)
+{
+    int p = 0;
+    for (int cc = DK_PARK_FROM; cc < 10; cc++)
+        for (int ii = 0; ii < 8; ii++) {
+            if (cc == c && ii == i) return p;
+            if ((S_COL_MASK[1][cc] >> ii) & 1u) p++;
+        }
+    return p;
+}
+__host__ __device__ constexpr int dk_count() { return dk_pos(10, 0); }
+
 // The dynamic models keep the integrator in the kernel itself (the code of dev_integrate_sens, written out): as a shared device
 // function the compiler forwarded the LDS-parked base sensitivities through registers (+45 spill stores, +14 %); only the
 // fkin6 integrator is shared with the persistent loop.
@@ -142,6 +158,15 @@ __global__ __launch_bounds__(64) void k_linearize_dyn(
                 if ((S_COL_MASK[1][c] >> i) & 1u) Sl[s_pos(1, c, i) * 64] = S[c][i];
             }
         }
+    // The stage derivatives dK of the last columns (delta_0, u_T, u_delta: 21 entries) wait in LDS as well while the model is evaluated -- what the
+    // 160 KB of a CU hold beside S at four waves: (55 + 21) x 512 B = 38 KB per wave.  They are fetched in front of the column's stage and put back
+    // behind it: same arithmetic, fewer values alive across the forward-AD evaluation (scratch 400 -> see profiles/r4/kernel_resources.txt).
+    double *Dl = S_IN_LDS ? Sl + s_count(1) * 64 : nullptr;
+#pragma unroll
+    for (int c = DK_PARK_FROM; c < 10; c++)
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (S_IN_LDS && ((S_COL_MASK[1][c] >> i) & 1u)) Dl[dk_pos(c, i) * 64] = 0.0;
 
     const double h = dt / M;
     for (int m = 0; m < M; m++) {
@@ -158,10 +183,21 @@ __global__ __launch_bounds__(64) void k_linearize_dyn(
 #pragma unroll
             for (int i = 0; i < 8; i++) X[i] = fma(ah, K[i], x[i]);
             if (MODEL == IHM2MPC_MODEL_FKIN6) fkin6_eval<true>(X, u_T, u_d, trk, K, J);
-            else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U>(X, u_T, u_d, trk, K, J);
+            else fdyn6_eval<true, MODEL == IHM2MPC_MODEL_FDYN6U, false, true>(X, u_T, u_d, trk, K, J);      // (with the scheduling fences between the wheels)
 #pragma unroll
             for (int i = 0; i < 8; i++) xacc[i] = fma(wh, K[i], xacc[i]);
-#define DYN_STAGE_COL(c) sens_col_stage<MODEL, c>(J, S[c], Sl, Sacc[c], dK[c], ah, wh);
+#define DYN_STAGE_COL(c)                                                                                                        \
+            {                                                                                                                   \
+                if (S_IN_LDS && c >= DK_PARK_FROM) {                                                                            \
+                    _Pragma("unroll") for (int i = 0; i < 8; i++)                                                               \
+                        if ((S_COL_MASK[1][c] >> i) & 1u) dK[c][i] = Dl[dk_pos(c, i) * 64];                                     \
+                }                                                                                                               \
+                sens_col_stage<MODEL, c>(J, S[c], Sl, Sacc[c], dK[c], ah, wh);                                                  \
+                if (S_IN_LDS && c >= DK_PARK_FROM) {                                                                            \
+                    _Pragma("unroll") for (int i = 0; i < 8; i++)                                                               \
+                        if ((S_COL_MASK[1][c] >> i) & 1u) Dl[dk_pos(c, i) * 64] = dK[c][i];                                     \
+                }                                                                                                               \
+            }
             FOR_ALL_COLS(DYN_STAGE_COL)
         }
 #pragma unroll
@@ -224,10 +260,10 @@ void ihm2_launch_linearize(ihm2mpc_handle *h)
     // per block of 64 intervals -- at any batch size, to measure it against the lane-per-interval kernel
     static const bool force_cols = getenv("IHM2MPC_LINEARIZE_COLS") && getenv("IHM2MPC_LINEARIZE_COLS")[0] == '1';
     if (h->cfg.model == IHM2MPC_MODEL_FDYN6U)
-        hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+        hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6U>, dim3(blocks), dim3(64), (s_count(1) + dk_count()) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else if (h->cfg.model == IHM2MPC_MODEL_FDYN6)
-        hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), s_count(1) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
+        hipLaunchKernelGGL(k_linearize_dyn<IHM2MPC_MODEL_FDYN6>, dim3(blocks), dim3(64), (s_count(1) + dk_count()) * 64 * sizeof(double), h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,
                            h->cfg.nknots, h->s_ref, h->kappa_ref, h->track_id, h->x, h->u, h->lin);
     else if (blocks <= 2 || force_cols)      // one or a few real-time controllers: the latency path (not bit-identical to the batch kernel, see above)
         hipLaunchKernelGGL(k_linearize_cols, dim3(blocks, 10), dim3(64), 0, h->stream, h->B, h->N, h->cfg.M, h->cfg.dt,

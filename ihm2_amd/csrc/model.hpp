@@ -306,6 +306,13 @@ __device__ __forceinline__ double mtanh(double x) { return nl_tanh(x); }
 __device__ __forceinline__ double msqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double val(double a) { return a; }
 
+// ---- from here to the end of the dynamic model: NO implicit contraction ----
+// With -ffp-contract=fast the back end fuses a*b + c*d into fma(a, b, c*d) or fma(c, d, a*b) by the use counts it happens to see, which depend
+// on what the function was inlined into: the same source gave the stand-alone linearisation kernel and the persistent loop results one rounding
+// apart once scheduling fences and LDS parking changed the surroundings (tests/test_gpu_closed_loop.py compares them bit for bit).  The dual-number
+// rules below say fma where they want one (product rule, chain rules); everything else is the operation it is written as, in every context.
+#pragma clang fp contract(off)
+
 // ---- sparse forward-mode duals: value + the directional derivatives named by the bits of MASK (bit k = d / d input k) ----
 // The force model's intermediates depend on one to five of its inputs (sin(delta): one; a rear slip angle: three; the load
 // transfer: all five).  Dual<5> carries five derivative slots through all of them, and without fast-math the compiler may not
@@ -454,9 +461,12 @@ template <unsigned TO, unsigned M> __device__ __forceinline__ void sd_assign(SD<
 // ---- fdyn6: Frenet 4-wheel Pacejka model (python/models.py:455-606), explicit form ----
 // The tyre/chassis force model maps (v_x, v_y, r, T, delta) to (v_x_dot, v_y_dot, r_dot).  It is written once over scalar types:
 // double for the plant, sparse duals seeded on the five inputs for the OCP (15 Jacobian entries by forward AD).
-template <bool UNCROSSED, typename TVX, typename TVY, typename TR, typename TT, typename TD, typename TO>
+template <bool UNCROSSED, bool FENCE = false, typename TVX, typename TVY, typename TR, typename TT, typename TD, typename TO>
 __device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r, const TT &Tq, const TD &delta, TO &vxd, TO &vyd, TO &rd)
 {
+    // (scheduling fences between the wheels: left to itself the scheduler interleaves the four wheels' slip angles and Pacejka curves -- with their
+    // partial derivatives some 150 values in flight -- and the linearisation kernel pays in scratch: 512 -> 400 B per lane, 6.4 -> 5.9 ms at 8192 x 40)
+#define WHEEL_FENCE() do { if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0); } while (0)
     TD sd, cd;
     msincos(delta, sd, cd);
     const auto F_down = v_x * v_x * (0.5 * k_Cdown);
@@ -469,22 +479,23 @@ __device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r,
     const auto v_lat_FL = cd * v_y_F - sd * v_x_FL, v_lat_FR = cd * v_y_F - sd * v_x_FR;
     const auto v_lat_R = v_y - r * k_lR;
     // slip angles: atan2(y, x) with x = smooth_abs_nonzero(.) > 0  ->  atan(y / x)
-    const auto a_FL = slip_angle_t(v_lat_FL, v_lon_FL);
-    const auto a_FR = slip_angle_t(v_lat_FR, v_lon_FR);
-    const auto a_RL = slip_angle_t(v_lat_R, v_x_FL);      // v_lon_RL = v_x - hx r
-    const auto a_RR = slip_angle_t(v_lat_R, v_x_FR);      // v_lon_RR = v_x + hx r
+    const auto a_FL = slip_angle_t(v_lat_FL, v_lon_FL); WHEEL_FENCE();
+    const auto a_FR = slip_angle_t(v_lat_FR, v_lon_FR); WHEEL_FENCE();
+    const auto a_RL = slip_angle_t(v_lat_R, v_x_FL); WHEEL_FENCE();      // v_lon_RL = v_x - hx r
+    const auto a_RR = slip_angle_t(v_lat_R, v_x_FR); WHEEL_FENCE();      // v_lon_RR = v_x + hx r
     // crossed slip angles exactly as models.py:543-546 (quirk Q3); order FL, FR, RL, RR.  UNCROSSED (model "fdyn6u") gives every
     // wheel its own slip angle: the crossed form is open-loop unstable (yaw eigenvalue +34 1/s at 10 m/s)
-    const auto glat0 = lat_pacejka_t(sd_sel<UNCROSSED>(a_FL, a_RR));
-    const auto glat1 = lat_pacejka_t(sd_sel<UNCROSSED>(a_FR, a_RL));
-    const auto glat2 = lat_pacejka_t(sd_sel<UNCROSSED>(a_RL, a_FR));
-    const auto glat3 = lat_pacejka_t(sd_sel<UNCROSSED>(a_RR, a_FL));
+    const auto glat0 = lat_pacejka_t(sd_sel<UNCROSSED>(a_FL, a_RR)); WHEEL_FENCE();
+    const auto glat1 = lat_pacejka_t(sd_sel<UNCROSSED>(a_FR, a_RL)); WHEEL_FENCE();
+    const auto glat2 = lat_pacejka_t(sd_sel<UNCROSSED>(a_RL, a_FR)); WHEEL_FENCE();
+    const auto glat3 = lat_pacejka_t(sd_sel<UNCROSSED>(a_RR, a_FL)); WHEEL_FENCE();
     const auto F_drag = -((v_x * v_x * k_Cr2 + v_x * k_Cr1 + k_Cr0) * mtanh(v_x * 10.0));
     const auto beta = matan((sd / cd) * k_rwd);                            // tan(delta) = sin / cos
     const auto r_kin = msqrt(v_x * v_x + v_y * v_y) * msin(beta) * (1.0 / k_lR);
     const auto dtau = (r_kin - r) * k_Ktv;
     const auto idenom = k_Cm0 / (F_down * (-0.25) - k_m * k_g);
     const auto gm = (Tq - dtau) * idenom, gp = (Tq + dtau) * idenom;      // glon: FL, RL = gm ; FR, RR = gp
+   
     const auto cx0 = gm * cd - glat0 * sd, cy0 = gm * sd + glat0 * cd;   // FL
     const auto cx1 = gp * cd - glat1 * sd, cy1 = gp * sd + glat1 * cd;   // FR
     const auto cz0 = cy0 * k_lF - cx0 * hx, cz1 = cx1 * hx + cy1 * k_lF;
@@ -495,10 +506,12 @@ __device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r,
     const auto X0 = F_drag - sumx * base, Y0 = -(sumy * base);
     const auto Xx = (cx0 + cx1 - gm - gp) * cx, Xy = (cx1 - cx0 + gp - gm) * cy;
     const auto Yx = (cy0 + cy1 - glat2 - glat3) * cx, Yy = (cy1 - cy0 + glat3 - glat2) * cy;
+   
     const auto a11 = -Xx + k_m, a12 = -Xy, a21 = -Yx, a22 = -Yy + k_m;
     const auto det = a11 * a22 - a12 * a21;
     const auto a_x = (X0 * a22 - a12 * Y0) / det;
     const auto a_y = (a11 * Y0 - a21 * X0) / det;
+   
     const auto lx = a_x * cx, ly = a_y * cy;
     const auto Fz0 = -(base - lx + ly), Fz1 = -(base - lx - ly), Fz2 = -(base + lx + ly), Fz3 = -(base + lx - ly);
     const auto Mz = cz0 * Fz0 + cz1 * Fz1 + cz2 * Fz2 + cz3 * Fz3;
@@ -506,6 +519,7 @@ __device__ inline void fdyn6_forces(const TVX &v_x, const TVY &v_y, const TR &r,
     sd_assign(vyd, a_y - v_x * r);
     sd_assign(rd, Mz * (1.0 / k_Iz));
 }
+#undef WHEEL_FENCE
 
 // ---- the force model WITH its Jacobian on a ROW of sixteen lanes: the collocation plants (python/main.py:395-400) ----
 // The collocation step has one lane per stage (a quad); the plant of ONE car leaves the other quads of a 16-lane row with nothing of their own to do,
@@ -657,7 +671,7 @@ __device__ inline void fdyn6_eval_quad(const int q, const double (&x)[8], double
 
 // xdot (and with WITH_JAC the structural non-zeros of its Jacobian, pattern JX_MASK[1] / JU_MASK[1])
 // ROW (collocation plants only, all sixteen lanes of a row on the same car and active): the wheels spread over the row's quads (fdyn6_forces_row)
-template <bool WITH_JAC, bool UNCROSSED, bool ROW = false>
+template <bool WITH_JAC, bool UNCROSSED, bool ROW = false, bool FENCE = false>
 __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_delta, TrackSeg &trk, double (&f)[8], double (&J)[8][10])
 {
     const double n = x[1], psi = x[2], v_x = x[3], v_y = x[4], r = x[5], T = x[6], delta = x[7];
@@ -676,7 +690,7 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
     if (WITH_JAC) {
         SD<0x1Fu> o0, o1, o2;
         if constexpr (ROW) fdyn6_forces_row<UNCROSSED>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
-        else fdyn6_forces<UNCROSSED>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
+        else fdyn6_forces<UNCROSSED, FENCE>(sd_seed<1u>(v_x), sd_seed<2u>(v_y), sd_seed<4u>(r), sd_seed<8u>(T), sd_seed<16u>(delta), o0, o1, o2);
         f[3] = o0.v; f[4] = o1.v; f[5] = o2.v;
 #pragma unroll
         for (int c = 0; c < 5; c++) { J[3][3 + c] = o0.d[c]; J[4][3 + c] = o1.d[c]; J[5][3 + c] = o2.d[c]; }
@@ -703,5 +717,7 @@ __device__ inline void fdyn6_eval(const double (&x)[8], double u_T, double u_del
         fdyn6_forces<UNCROSSED>(v_x, v_y, r, T, delta, f[3], f[4], f[5]);
     }
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace ihm2
