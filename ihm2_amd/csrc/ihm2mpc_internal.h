@@ -13,6 +13,12 @@
 
 #include "../../include/ihm2mpc.h"
 
+// Floating-point contraction.  The sources are compiled with -ffp-contract=on (Makefile) and switch to `fast` HERE, for everything that follows in
+// the translation unit: a*b + c is then fused wherever the two operations meet, as before -- but by the `contract` flag on the operations, not by
+// the back end's global switch (-ffp-contract=fast), which fuses every multiply-add pair it sees and cannot be turned off for a region.  The
+// dynamic model's section of model.hpp turns contraction OFF: its results must not depend on what it is inlined into (NOTES.md R4.11).
+#pragma clang fp contract(fast)
+
 #define NX 8
 #define NU 2
 #define NZ 10

@@ -4,7 +4,7 @@ with the Makefile's flags; the QP source once per instantiation set).  usage: to
 import os, re, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "ihm2_amd", "csrc")
-BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 QP = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 jobs = [(f, []) for f in ("kernels_misc.hip", "kernels_linearize.hip", "kernels_cart.hip", "kernels_dyn10.hip", "kernels_sqp.hip", "kernels_irk.hip")]
 jobs += [("kernels_qp.hip", ["-DQP_SET=0"] + QP), ("kernels_qp.hip", ["-DQP_SET=1"] + QP), ("kernels_qp.hip", ["-DQP_SET=2"] + QP)]

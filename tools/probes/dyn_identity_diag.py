@@ -27,6 +27,7 @@ for model, plant in (("fdyn6u", 2), ("fdyn6u", 0)):
         print(model, plant, k, "equal" if np.array_equal(a, c) else f"DIFFER max abs {d.max():.3e} rel {np.max(d / np.maximum(1e-300, np.abs(c))):.3e} count {int((d > 0).sum())} of {d.size}", flush=True)
     a, c = out[0]["A"], out[1]["A"]
     pos = np.argwhere(a != c)
+    if not len(pos): continue
     from collections import Counter
     print("A positions (row, col) -> count:", sorted(Counter((int(p[-2]), int(p[-1])) for p in pos).items()))
     i = tuple(pos[0]); print("sample", i, repr(a[i]), repr(c[i]))
