@@ -307,10 +307,12 @@ __device__ __forceinline__ double msqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double val(double a) { return a; }
 
 // ---- from here to the end of the dynamic model: NO implicit contraction ----
-// With -ffp-contract=fast the back end fuses a*b + c*d into fma(a, b, c*d) or fma(c, d, a*b) by the use counts it happens to see, which depend
-// on what the function was inlined into: the same source gave the stand-alone linearisation kernel and the persistent loop results one rounding
-// apart once scheduling fences and LDS parking changed the surroundings (tests/test_gpu_closed_loop.py compares them bit for bit).  The dual-number
-// rules below say fma where they want one (product rule, chain rules); everything else is the operation it is written as, in every context.
+// Left to fuse, the back end turns a*b + c*d into fma(a, b, c*d) or fma(c, d, a*b) by the use counts it happens to see, which depend on what the
+// function was inlined into: the same source gave the stand-alone linearisation kernel and the persistent loop torque-direction derivatives one
+// rounding apart once scheduling fences and LDS parking changed the surroundings (tests/test_gpu_closed_loop.py compares the two bit for bit).
+// The dual-number rules below say fma where they want one (product rule, chain rules); everything else is the operation it is written as, in
+// every context.  (This works because the library is compiled with -ffp-contract=on and asks for `fast` by pragma, ihm2mpc_internal.h: the
+// command-line `fast` is a global switch of the back end that no pragma turns off.)
 #pragma clang fp contract(off)
 
 // ---- sparse forward-mode duals: value + the directional derivatives named by the bits of MASK (bit k = d / d input k) ----
