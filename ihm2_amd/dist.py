@@ -201,6 +201,7 @@ class RankContext:
         self.addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         self.port = int(os.environ.get("MASTER_PORT", "29500"))
         force = os.environ.get("IHM2_FORCE_DIST") == "1"          # rehearse the exchange path with one rank
+        requested = carrier
         self.rehearsal = device is not None or backend != "nccl"   # ranks put on one device on purpose / no GPU collective at all
         if self.world == 1 and not force:
             carrier = "none"
@@ -209,19 +210,27 @@ class RankContext:
             # only where RCCL cannot run (gloo: the rehearsal of N ranks on one device / on the CPU)
             carrier = "rccl" if backend == "nccl" else "torch"
         self.carrier, self.backend = carrier, backend
+        self.carrier_was_auto = carrier == "rccl" and requested == "auto"
+        self.fallback = None          # why the default carrier was left, if it was (goes into the bench line)
         self.on_gpu = backend == "nccl"
         self._dist = None
         self._native = None
         if carrier == "torch":
-            import torch
-            import torch.distributed as dist
+            self._init_torch()
 
-            if self.on_gpu:
-                torch.cuda.set_device(self.device)
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.device))
-            else:
-                dist.init_process_group(backend="gloo")
-            self._dist = dist
+    def _init_torch(self, timeout_s: float | None = None) -> None:
+        import datetime
+
+        import torch
+        import torch.distributed as dist
+
+        kw = {} if timeout_s is None else {"timeout": datetime.timedelta(seconds=timeout_s)}
+        if self.on_gpu:
+            torch.cuda.set_device(self.device)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.device), **kw)
+        else:
+            dist.init_process_group(backend="gloo", **kw)
+        self._dist = dist
 
     def bounds(self, total: int) -> tuple[int, int]:
         return shard_bounds(total, self.world, self.rank)
@@ -232,7 +241,23 @@ class RankContext:
         if self.carrier == "rccl":
             if self._native is not None:
                 self._native.free()
-            self._native = NativeComm(solver, total, self.world, self.rank, self.addr, self.port + 23)
+                self._native = None
+            try:
+                self._native = NativeComm(solver, total, self.world, self.rank, self.addr, self.port + 23)
+            except Exception as e:
+                # The default carrier could not be built (librccl not resolvable, the id channel's port taken, ncclCommInitRank refusing):
+                # causes of that kind hit every rank of a node alike, so every rank lands here and the three exchanges -- barrier, max,
+                # the final gather of 20 B per instance -- go over torch.distributed's gloo on HOST buffers, with the reason in the line.
+                # Not over torch's nccl backend: torch imported after this library binds its c10d to the HIP runtime and the librccl
+                # already mapped from /opt/rocm instead of its own bundled ones (measured: "No HIP GPUs are available", or a gather that
+                # returns stale memory; tools/probes/torch_gather_diag.py).  An explicit `--carrier rccl` is not second-guessed, and a
+                # failure on SOME ranks only ends in the bounded rendezvous timeout below instead of a result.
+                if not self.carrier_was_auto:
+                    raise
+                self.fallback = f"{type(e).__name__}: {e}"
+                self.carrier = "torch"
+                self.on_gpu = False
+                self._init_torch(timeout_s=120.0)
 
     def barrier(self, solver=None) -> None:
         if solver is not None:
@@ -294,13 +319,15 @@ class RankContext:
 
     def describe(self) -> str:
         return {"none": "none (one GPU)", "rccl": "RCCL all-gather of (u0, status) behind the C ABI (ihm2mpc_comm_*, no PyTorch)",
-                "torch": f"torch.distributed ({'nccl = RCCL' if self.on_gpu else 'gloo'}) all_gather of (u0, status)"}[self.carrier]
+                "torch": f"torch.distributed ({'nccl = RCCL' if self.on_gpu else 'gloo, host buffers'}) all_gather of (u0, status)"}[self.carrier]
 
     def verify(self, solver) -> dict:
         """What actually answered: the communicator's rank count and every rank's device, gathered over the carrier itself.  Raises
         ``SystemExit`` when fewer distinct devices than ranks did (unless the run is a declared rehearsal).  The returned record goes
         into the bench line (``config.collective``)."""
         rec = {"carrier": self.describe(), "world": self.world}
+        if self.fallback is not None:
+            rec["fallback_from_rccl_carrier"] = self.fallback
         if self._native is not None:
             count, ids = self._native.info()
             rec.update(rccl_ranks=count, devices=[pci_name(i) for i in ids], distinct_devices=require_distinct_devices(ids, self.world, self.rehearsal))

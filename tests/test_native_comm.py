@@ -90,3 +90,64 @@ def test_bench_over_the_native_communicator_with_one_forced_rank(extra):
     col = line["config"]["collective"]
     assert col["rccl_ranks"] == 1 and col["distinct_devices"] == 1 and len(col["devices"]) == 1 and "RCCL" in col["carrier"]
     assert line["n_gpus"] == 1 and line["value"] > 0 and "gather_ms" in line
+
+
+def _one_forced_rank(monkeypatch, port):
+    for k, v in dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), IHM2_FORCE_DIST="1").items():
+        monkeypatch.setenv(k, v)
+
+
+def test_default_carrier_falls_back_when_its_communicator_cannot_be_built(monkeypatch):
+    """`--carrier auto` = the C ABI's own RCCL communicator; if that cannot be BUILT (librccl not resolvable, the id channel's port taken --
+    the same on every rank of a node) the job goes on over torch.distributed and says why; an explicit `--carrier rccl` raises."""
+    from ihm2_amd import dist
+
+    _one_forced_rank(monkeypatch, 29633)
+
+    def broken(*a, **k):
+        raise RuntimeError("librccl.so: cannot open shared object file")
+
+    started = []
+    monkeypatch.setattr(dist, "NativeComm", broken)
+    monkeypatch.setattr(dist.RankContext, "_init_torch", lambda self, timeout_s=None: started.append(timeout_s))
+    ctx = dist.RankContext(carrier="auto", backend="nccl")
+    assert ctx.carrier == "rccl" and ctx.fallback is None
+    ctx.attach(object(), 8)
+    assert ctx.carrier == "torch" and started == [120.0] and "librccl" in ctx.fallback
+    assert "gloo" in ctx.describe() and not ctx.on_gpu          # host buffers: torch's nccl backend must not be started after this library
+    explicit = dist.RankContext(carrier="rccl", backend="nccl")
+    with pytest.raises(RuntimeError):
+        explicit.attach(object(), 8)
+    assert explicit.carrier == "rccl" and started == [120.0]
+
+
+@pytest.mark.gpu
+def test_fallback_carrier_gathers_the_same_results(track, monkeypatch):
+    """The fallback for real on one forced rank, in a process that has the product's HIP runtime and RCCL mapped already: the native
+    communicator refused, torch.distributed's gloo takes the three exchanges on host buffers."""
+    from ihm2_amd import dist
+    from ihm2_amd.solver import BatchedOcpSolver
+
+    _one_forced_rank(monkeypatch, 29635)
+
+    def broken(*a, **k):
+        raise OSError("address already in use")
+
+    monkeypatch.setattr(dist, "NativeComm", broken)
+    B = 70
+    s = BatchedOcpSolver(make_ocp(), B, track.s_ref, track.kappa_ref)
+    s.set_x0(sample_x0(track, B, seed=4)); s.init_guess(); s.prepare_step(40.0); st = s.solve()
+    ctx = dist.RankContext(carrier="auto", backend="nccl")
+    try:
+        ctx.attach(s, B)
+        assert ctx.carrier == "torch" and "address already in use" in ctx.fallback
+        ctx.barrier(s)
+        assert ctx.max(3.25) == 3.25 and ctx.sum(2.0) == 2.0
+        u0, status = ctx.gather_results(s)
+        np.testing.assert_array_equal(status, st)
+        np.testing.assert_array_equal(u0, s.get_u0())
+        rec = ctx.verify(s)
+        assert rec["distinct_devices"] == 1 and "gloo" in rec["carrier"] and "address already in use" in rec["fallback_from_rccl_carrier"]
+    finally:
+        ctx.close()
+        s.free()
