@@ -46,6 +46,17 @@ def test_bench_starts_its_own_ranks_and_gathers_in_global_order():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and sum(d["status_counts"].values()) == 101
 
 
+def test_default_carrier_refused_by_rccl_goes_on_over_gloo_and_says_so():
+    """Two self-started ranks on ONE device with the default carrier: the id channel and RCCL's bootstrap run between two real processes, then
+    `ncclCommInitRank` refuses the duplicate device on both ranks -- the failure path of the default carrier for real -- and the exchanges go over
+    gloo on host buffers with the reason in the line (dist.py::RankContext.attach)."""
+    d = _run("--gpus", "2", "--device", "0", "--steps", "4", "--warmup", "1", "--batch", "96", "--no-cpu-baseline", "--no-extras")
+    col = d["config"]["collective"]
+    assert d["n_gpus"] == 2 and col["world"] == 2 and "gloo" in col["carrier"] and "rehearsal" in col
+    assert "ncclCommInitRank" in col["fallback_from_rccl_carrier"]
+    assert sum(d["status_counts"].values()) == 192
+
+
 def test_sharded_config3_and_config4_lines():
     d = _run("--config", "3", "--gpus", "2", "--device", "0", "--dist-backend", "gloo", "--batch", "256", "--steps", "3", "--warmup", "2")
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["success_fraction"] > 0.8
