@@ -349,6 +349,16 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def claim_stdout():
+    """stdout carries the JSON line and nothing else.  Libraries write to file descriptor 1 behind Python's back (RCCL's version banner on
+    ncclCommInitRank, gloo's connection notes -- seen under `python -m torch.distributed.run` with two ranks): descriptor 1 is pointed at
+    stderr for them, and ``sys.stdout`` keeps the original descriptor for the line."""
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(line_fd, "w")
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -363,6 +373,7 @@ def main():
         from ihm2_amd.dist import spawn_ranks
 
         raise SystemExit(spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    claim_stdout()             # after the branch above: the ranks bench.py starts inherit descriptor 1 as it was and claim it themselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -19,6 +19,7 @@ def _run(*args, timeout=600):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]            # ONE JSON line, from rank 0
+    assert r.stdout.strip().splitlines() == lines, r.stdout[-2000:]      # and nothing else on stdout (RCCL's banner, gloo's notes go to stderr)
     return json.loads(lines[0])
 
 
@@ -78,3 +79,21 @@ def test_a_rank_without_a_device_fails_the_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-extras"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_the_launch_line_of_the_driver_prints_one_line_and_nothing_else():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` as the driver
+    starts it, both ranks on the one device of the box (`--device 0`, a declared rehearsal): the default carrier finds RCCL refusing the duplicate
+    device and takes gloo; stdout is the line alone.  Without `--device` rank 1 has no device and the run fails without a line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    tail = ["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "96", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(launch + ["--master-port", "29541", os.path.join(ROOT, "bench.py")] + tail + ["--device", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[-2000:]
+    d = json.loads(out[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 192 and d["config"]["collective"]["world"] == 2
+    r = subprocess.run(launch + ["--master-port", "29543", os.path.join(ROOT, "bench.py")] + tail, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+    assert "out of range" in r.stderr
