@@ -57,8 +57,10 @@ def shard_sizes(total: int, world: int) -> np.ndarray:
     return np.array([shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)], dtype=np.int32)
 
 
-def exchange_bytes(payload: bytes | None, nbytes: int, world: int, rank: int, addr: str, port: int, timeout: float = 120.0) -> bytes:
-    """Rank 0 hands ``payload`` (``nbytes`` long) to every other rank over TCP: the side channel of the RCCL unique id."""
+def exchange_bytes(payload: bytes | None, nbytes: int, world: int, rank: int, addr: str, port: int, timeout: float = 45.0) -> bytes:
+    """Rank 0 hands ``payload`` (``nbytes`` long) to every other rank over TCP: the side channel of the RCCL unique id.  The wait is
+    bounded well below the 120 s rendezvous of the fallback carrier (:meth:`RankContext.attach`): if rank 0 cannot bind the port it
+    is in that rendezvous at once, and the others must give up here early enough to still meet it there."""
     if world == 1:
         return payload
     if rank == 0:
