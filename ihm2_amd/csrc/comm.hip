@@ -277,7 +277,7 @@ int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value)
 }
 
 // What the communicator actually spans, for the record of a multi-GPU run: *count <- ncclCommCount, device_ids (world) <- the PCI identity
-// (domain << 24 | bus << 8 | device) of the device every rank computes on, gathered over the communicator itself -- N ranks on fewer
+// (domain << 24 | bus << 8 | device, a tag of the device's UUID above bit 48) of the device every rank computes on, gathered over the communicator itself -- N ranks on fewer
 // than N devices show up as repeated identities.
 int ihm2mpc_comm_info(ihm2mpc_handle *h, int32_t *count, int64_t *device_ids)
 {
@@ -291,7 +291,15 @@ int ihm2mpc_comm_info(ihm2mpc_handle *h, int32_t *count, int64_t *device_ids)
     HIPC_TRY(hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, h->cfg.device));
     HIPC_TRY(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, h->cfg.device));
     HIPC_TRY(hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, h->cfg.device));
-    const long long mine = ((long long)dom << 24) | ((long long)bus << 8) | (long long)dev;
+    long long mine = ((long long)dom << 24) | ((long long)bus << 8) | (long long)dev;
+    // partitions of one package share (domain, bus, device): fifteen bits of a hash of the device's UUID ride in bits 48..62, so that two logical
+    // devices are told apart and two ranks on ONE logical device still are not (no UUID: tag 0, the PCI identity alone decides)
+    hipUUID uu;
+    if (hipDeviceGetUuid(&uu, h->cfg.device) == hipSuccess) {
+        unsigned long long f = 1469598103934665603ull;
+        for (unsigned char b : uu.bytes) f = (f ^ b) * 1099511628211ull;
+        mine |= (long long)((f ^ (f >> 15) ^ (f >> 30) ^ (f >> 45)) & 0x7FFFull) << 48;
+    } else (void)hipGetLastError();
     if (!c->ids) HIPC_TRY(hipMalloc((void **)&c->ids, (size_t)(1 + c->world) * sizeof(long long)));
     HIPC_TRY(hipMemcpyAsync(c->ids, &mine, sizeof mine, hipMemcpyHostToDevice, h->stream));
     NCCL_TRY(rccl.AllGather(c->ids, c->ids + 1, 1, ncclInt64, c->comm, h->stream));

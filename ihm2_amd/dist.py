@@ -142,7 +142,8 @@ class NativeComm:
 
 def pci_name(ident: int) -> str:
     """``domain:bus:device`` of a device identity of ``ihm2mpc_comm_info``."""
-    return f"{ident >> 24:04x}:{(ident >> 8) & 0xFFFF:02x}:{ident & 0xFF:02x}"
+    tag = (ident >> 48) & 0x7FFF
+    return f"{(ident >> 24) & 0xFFFF:04x}:{(ident >> 8) & 0xFFFF:02x}:{ident & 0xFF:02x}" + (f" uuid~{tag:04x}" if tag else "")
 
 
 def require_distinct_devices(device_ids, world: int, rehearsal: bool = False) -> int:

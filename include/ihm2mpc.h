@@ -350,7 +350,8 @@ int ihm2mpc_comm_init(ihm2mpc_handle *h, int32_t world, int32_t rank, const uint
 int ihm2mpc_comm_allgather_results(ihm2mpc_handle *h, double *u0_all, int32_t *status_all);      /* host, rank order, on every rank */
 int ihm2mpc_comm_allreduce_max(ihm2mpc_handle *h, double *value);      /* in place; doubles as a barrier */
 /* what the communicator spans, for the record of a multi-GPU run: *count <- ncclCommCount; device_ids (world) <- the PCI identity
- * (domain << 24 | bus << 8 | device) of every rank's device, gathered over the communicator: N ranks on fewer than N devices repeat one */
+ * (domain << 24 | bus << 8 | device; bits 48..62: a tag of the device's UUID, which tells partitions of one package apart) of every rank's
+ * device, gathered over the communicator: N ranks on fewer than N devices repeat one */
 int ihm2mpc_comm_info(ihm2mpc_handle *h, int32_t *count, int64_t *device_ids);
 int ihm2mpc_comm_free(ihm2mpc_handle *h);
 

@@ -166,6 +166,11 @@ def test_a_job_is_reported_as_n_gpus_only_if_n_distinct_devices_answered():
     with pytest.raises(SystemExit, match="answered"):
         require_distinct_devices(ids[:7], 8)                           # a rank is missing
     assert require_distinct_devices([ids[0]] * 2, 2, rehearsal=True) == 1
+    # partitions of one package share the PCI triple and differ in the UUID tag (bits 48..62): distinct devices; the name shows both
+    parts = [ids[2] | (t << 48) for t in (0x1234, 0x0777)]
+    assert require_distinct_devices(parts, 2) == 2 and pci_name(parts[0]) == "0000:65:00 uuid~1234"
+    with pytest.raises(SystemExit, match="1 distinct devices"):
+        require_distinct_devices([parts[0]] * 2, 2)
 
 
 def test_bench_refuses_one_gpu_workloads_on_several_ranks():
